@@ -1,0 +1,133 @@
+"""The CPU oracle against the golden vectors produced by the reference's own modules
+(tools/gen_golden.py).  CPU only; sized to run in well under a minute."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_fixture, regenerate, sample_like, torch_sd
+from oracle import act_ref as R
+from actmi import weights as W
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_c3", "full3"])
+def test_oracle_inference_matches_reference(name):
+    z, cfg = load_fixture(name)
+    sd_np, inp = regenerate(z, cfg)
+    sd = torch_sd(sd_np)
+    image = torch.from_numpy(W.u8_nhwc_to_f32_nchw(inp["image_u8"]))
+    qpos = torch.from_numpy(inp["qpos"])
+    stages = {}
+    with torch.no_grad():
+        a_hat, is_pad_hat, _, _ = R.detrvae_forward(sd, cfg, qpos, R.normalize_image(image), p="model.", stages=stages)
+    # tolerance: fp32 CPU, same op order -> differences are thread-partition noise only
+    assert np.abs(a_hat.numpy() - z["infer.a_hat"]).max() < 2e-5
+    assert np.abs(sample_like(is_pad_hat.numpy(), z) - z["infer.is_pad_hat"].reshape(-1)).max() < 2e-5
+    for k in ("cam0_conv1", "cam0_maxpool", "cam0_layer1", "cam0_layer4", "src", "memory"):
+        got = sample_like(stages[k].numpy(), z)
+        exp = z["stage." + k].reshape(-1)
+        assert got.shape == exp.shape, k
+        assert np.abs(got - exp).max() < 5e-5 * max(1.0, np.abs(exp).max()), k
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_c3"])
+def test_oracle_training_losses_and_grads(name):
+    z, cfg = load_fixture(name)
+    sd_np, inp = regenerate(z, cfg)
+    # single thread: torch CPU autograd is not run-to-run reproducible for the 1x1/s2 conv wgrad otherwise
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    sd = {k: v.clone().requires_grad_(not W.is_buffer(k[len("model."):])) for k, v in torch_sd(sd_np).items()}
+    image = torch.from_numpy(W.u8_nhwc_to_f32_nchw(inp["image_u8"]))
+    out = R.policy_call(sd, cfg, torch.from_numpy(inp["qpos"]), image, torch.from_numpy(inp["actions"]),
+                        torch.from_numpy(inp["is_pad"]), torch.from_numpy(z["train.eps"]))
+    for k in ("l1", "kl", "loss"):
+        assert abs(float(out[k].detach()) - float(z["train." + k][0])) < 5e-5 * max(1.0, abs(float(out[k].detach()))), k
+    assert np.abs(out["mu"].detach().numpy() - z["train.mu"]).max() < 2e-5
+    assert np.abs(out["a_hat"].detach().numpy() - z["train.a_hat"]).max() < 2e-5
+    out["loss"].backward()
+    torch.set_num_threads(nthreads)
+    names = [str(n) for n in z["grad_names"]]
+    l2 = z["grad_l2"]
+    none = set(str(n) for n in z["grad_none"])
+    for n, ref_l2 in zip(names, l2):
+        g = sd["model." + n].grad
+        if n in none:
+            # is_pad_head never receives a gradient
+            assert g is None or float(g.abs().max()) == 0.0, n
+            continue
+        assert g is not None, n
+        got = float(g.double().norm())
+        assert abs(got - ref_l2) <= 2e-4 * max(ref_l2, 1e-3), (n, got, ref_l2)
+    # dead decoder layers get exactly-zero (not None) gradients (quirk 1)
+    if cfg.dec_layers > 1:
+        i = names.index("transformer.decoder.layers.1.linear1.weight")
+        assert l2[i] == 0.0
+    for k in z.files:
+        if k.startswith("grad.") and name == "tiny":
+            g = sd["model." + k[5:]].grad.numpy()
+            exp = z[k]
+            assert np.abs(g - exp).max() <= 1e-4 * max(np.abs(exp).max(), 1e-3), k
+
+
+def test_full4_fixture_is_consistent():
+    """Full-size fixture: only hashes / shapes on CPU here (the forward itself runs in the gpu tests)."""
+    z, cfg = load_fixture("full4")
+    assert cfg.num_tokens == 1202 and cfg.num_cams == 4
+    assert z["infer.a_hat"].shape == (2, 100, 16)
+    assert int(z["n_params"]) == 117_431_073 or int(z["n_params"]) > 117_000_000
+
+
+def test_sinusoid_and_pos_table():
+    z, cfg = load_fixture("tiny")
+    sd_np, _ = regenerate(z, cfg)
+    assert sd_np["pos_table"].shape == (1, cfg.num_queries + 2, cfg.hidden_dim)
+    p = R.position_embedding_sine(3, 5, 16)
+    assert p.shape == (1, 32, 3, 5)
+
+
+def test_temporal_ensemble_reference_semantics():
+    """Transcription check of imitate_episodes.py:402-411 on a scripted stream, incl. an exact-zero row."""
+    T, Q, A = 12, 5, 16
+    ens = R.TemporalEnsembleRef(T, Q, A)
+    rng = np.random.default_rng(0)
+    chunks = rng.standard_normal((T, 1, Q, A)).astype(np.float32)
+    chunks[3, 0, 2, 7] = 0.0            # row written at t=3 for step t=5 has a zero -> not "populated"
+    for t in range(T):
+        raw, pop = ens.step(t, torch.from_numpy(chunks[t]))
+        assert raw.dtype == torch.float64 and raw.shape == (1, A)
+        rows = [r for r in range(max(0, t - Q + 1), t + 1) if not (t == 5 and r == 3)]
+        w = np.exp(-0.01 * np.arange(len(rows)))
+        w /= w.sum()
+        exp = sum(wi * chunks[r, 0, t - r].astype(np.float64) for wi, r in zip(w, rows))
+        assert np.allclose(raw.numpy()[0], exp, atol=1e-12)
+        assert int(pop.sum()) == len(rows)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference only exists in the authoring container")
+def test_reference_reproduces_committed_fixture():
+    """Re-run the reference's own modules and compare with the committed tiny fixture (authoring container only)."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(root, "tools", "gen_golden.py"))
+    gg = importlib.util.module_from_spec(spec)
+    saved = {k: sys.modules.get(k) for k in ("policy", "IPython", "torchvision")}
+    spec.loader.exec_module(gg)
+    ref = gg.import_reference()
+    try:
+        z, cfg = load_fixture("tiny")
+        sd_np, inp = regenerate(z, cfg)
+        pol = gg.build_reference_policy(ref, cfg)
+        pol.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+        pol.eval()
+        with torch.no_grad():
+            a = pol(torch.from_numpy(inp["qpos"]), torch.from_numpy(W.u8_nhwc_to_f32_nchw(inp["image_u8"])))
+        assert np.abs(a.numpy() - z["infer.a_hat"]).max() < 1e-6
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
