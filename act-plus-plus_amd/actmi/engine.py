@@ -1,0 +1,151 @@
+"""Python handle of one libactmi context: owns nothing but the C handle; tensors stay torch-owned.
+
+Mirrors what ``build_ACT_model_and_optimizer`` returns in the reference (detr/main.py:92-112): a model object with
+``num_queries`` / ``encoder`` attributes that ``imitate_episodes.py`` reads, loadable from / dumpable to the
+reference's state_dict.
+"""
+from collections import OrderedDict
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .config import ACTConfig
+from .weights import act_state_dict_spec, is_buffer
+
+
+class ACTEngine:
+    def __init__(self, cfg: ACTConfig, max_batch: int = 8, device: str = "cuda:0", training: bool = False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ACTEngine needs an MI355X (torch.cuda.is_available() is False); no CPU fallback exists")
+        self.cfg = cfg.validate()
+        self.device = torch.device(device)
+        self.max_batch = int(max_batch)
+        self.lib = L.load()
+        torch.cuda.set_device(self.device)
+        c = L.ActmiConfig(num_cams=cfg.num_cams, image_h=cfg.image_h, image_w=cfg.image_w, base_width=cfg.base_width,
+                          hidden_dim=cfg.hidden_dim, nheads=cfg.nheads, dim_feedforward=cfg.dim_feedforward,
+                          enc_layers=cfg.enc_layers, dec_layers=cfg.dec_layers, num_queries=cfg.num_queries,
+                          state_dim=cfg.state_dim, action_dim=cfg.action_dim, latent_dim=cfg.latent_dim,
+                          has_cvae_encoder=0 if cfg.no_encoder else 1, max_batch=self.max_batch,
+                          enable_training=1 if training else 0, kl_weight=float(cfg.kl_weight))
+        h = C.c_void_p()
+        rc = self.lib.actmi_create(C.byref(c), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"actmi_create failed ({rc}): {self.lib.actmi_last_error(None).decode()}")
+        self.h = h
+        self.spec = act_state_dict_spec(cfg)
+        self._finalized = False
+        # attributes imitate_episodes.py touches on policy.model
+        self.num_queries = cfg.num_queries
+        self.encoder = None if cfg.no_encoder else True
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.actmi_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- parameters ---------------------------------------------------------------------------
+    def load_state_dict(self, sd, prefix: str = "", strict: bool = True):
+        """sd: {key: numpy array | torch tensor}. Returns (missing_keys, unexpected_keys) like nn.Module."""
+        missing, unexpected = [], []
+        for k in self.spec:
+            if prefix + k not in sd:
+                missing.append(prefix + k)
+        for k in sd:
+            kk = k[len(prefix):] if k.startswith(prefix) else None
+            if kk is None or kk not in self.spec:
+                if not (kk and kk.endswith("num_batches_tracked")):      # dropped by FrozenBatchNorm2d, backbone.py:37-41
+                    unexpected.append(k)
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"state_dict mismatch: missing {missing[:5]}... unexpected {unexpected[:5]}...")
+        for k, shape in self.spec.items():
+            if prefix + k not in sd:
+                continue
+            v = sd[prefix + k]
+            if isinstance(v, np.ndarray):
+                v = torch.from_numpy(np.ascontiguousarray(v))
+            v = v.detach().to(torch.float32).contiguous()
+            if tuple(v.shape) != tuple(shape):
+                raise RuntimeError(f"shape mismatch for {k}: {tuple(v.shape)} vs {tuple(shape)}")
+            shp = (C.c_int64 * len(shape))(*shape)
+            is_dev = 1 if v.is_cuda else 0
+            L.check(self.lib.actmi_set_param(self.h, k.encode(), C.c_void_p(v.data_ptr()), shp, len(shape), is_dev),
+                    self.h, f"set_param({k})")
+        self._finalized = False
+        return missing, unexpected
+
+    def state_dict(self, prefix: str = "") -> "OrderedDict[str, torch.Tensor]":
+        out = OrderedDict()
+        for k, shape in self.spec.items():
+            t = torch.empty(shape, dtype=torch.float32)
+            L.check(self.lib.actmi_get_param(self.h, k.encode(), C.c_void_p(t.data_ptr()), t.numel() * 4, 0), self.h,
+                    f"get_param({k})")
+            out[prefix + k] = t
+        return out
+
+    def finalize(self):
+        L.check(self.lib.actmi_finalize(self.h, L.current_stream_ptr()), self.h, "finalize")
+        self._finalized = True
+
+    # ---- forward ------------------------------------------------------------------------------
+    def _image_fmt(self, image: torch.Tensor, B: int):
+        cfg = self.cfg
+        if image.dtype == torch.uint8:
+            want = (B, cfg.num_cams, cfg.image_h, cfg.image_w, 3)
+            fmt = L.IMG_U8_NHWC
+        elif image.dtype == torch.float32:
+            want = (B, cfg.num_cams, 3, cfg.image_h, cfg.image_w)
+            fmt = L.IMG_F32_NCHW
+        else:
+            raise TypeError(f"image dtype {image.dtype} not supported (uint8 NHWC or float32 NCHW)")
+        if tuple(image.shape) != want:
+            raise ValueError(f"image shape {tuple(image.shape)} != {want}")
+        return fmt
+
+    def forward_infer(self, qpos: torch.Tensor, image: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        if not self._finalized:
+            self.finalize()
+        cfg = self.cfg
+        B = qpos.shape[0]
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} > max_batch {self.max_batch}")
+        if not (qpos.is_cuda and image.is_cuda):
+            raise ValueError("qpos and image must be CUDA tensors on the engine's device")
+        qpos = qpos.to(torch.float32).contiguous()
+        image = image.contiguous()
+        fmt = self._image_fmt(image, B)
+        if tuple(qpos.shape) != (B, cfg.state_dim):
+            raise ValueError(f"qpos shape {tuple(qpos.shape)} != {(B, cfg.state_dim)}")
+        if out is None:
+            out = torch.empty((B, cfg.num_queries, cfg.action_dim), dtype=torch.float32, device=qpos.device)
+        L.check(self.lib.actmi_forward_infer(self.h, C.c_void_p(qpos.data_ptr()), C.c_void_p(image.data_ptr()), fmt, B,
+                                             C.c_void_p(out.data_ptr()), L.current_stream_ptr()), self.h, "forward_infer")
+        return out
+
+    # ---- debug --------------------------------------------------------------------------------
+    def debug_stop_after(self, stage: str):
+        L.check(self.lib.actmi_debug_stop_after(self.h, (stage or "").encode()), self.h, "debug_stop_after")
+
+    def debug_tensor(self, name: str) -> torch.Tensor:
+        p, n = C.c_void_p(), C.c_int64()
+        L.check(self.lib.actmi_debug_tensor(self.h, name.encode(), C.byref(p), C.byref(n)), self.h, f"debug_tensor({name})")
+        t = torch.empty(n.value, dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize()
+        src = _from_ptr(p.value, n.value, self.device)     # wrap the raw pointer, then D2D copy through torch
+        t.copy_(src)
+        torch.cuda.synchronize()
+        return t
+
+
+def _from_ptr(ptr: int, numel: int, device) -> torch.Tensor:
+    """View raw device memory as a float32 torch tensor (no ownership)."""
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (numel,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+    return torch.as_tensor(h, device=device)

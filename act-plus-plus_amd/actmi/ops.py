@@ -1,0 +1,145 @@
+"""Thin torch-tensor wrappers over the kernel-level C entry points (used by tests, the eval harness and bench)."""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def gemm(A, W, bias=None, scale=None, res=None, res_mod=0, relu=False, a_add=None, add_mod=0, add_ncols=0, rowmap=None,
+         out=None, out_rows=None):
+    """out[rowmap(m)] = act((A' @ W.T) * scale + bias + res[m % res_mod]); A [M,K], W [N,K] row-major f32 cuda."""
+    lib = L.load()
+    M, K = A.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.zeros((out_rows or M, N), dtype=torch.float32, device=A.device)
+    d = L.GemmDesc()
+    d.A, d.lda, d.mode = A.data_ptr(), A.stride(0), 0
+    if a_add is not None:
+        d.A_add, d.ld_add, d.add_mod, d.add_ncols = a_add.data_ptr(), a_add.stride(0), add_mod, add_ncols
+    d.Bw, d.ldb = W.data_ptr(), W.stride(0)
+    d.scale = scale.data_ptr() if scale is not None else None
+    d.bias = bias.data_ptr() if bias is not None else None
+    if res is not None:
+        d.res, d.ldres, d.res_mod = res.data_ptr(), res.stride(0), res_mod
+    d.relu = 1 if relu else 0
+    d.C, d.ldc = out.data_ptr(), out.stride(0)
+    d.rowmap = rowmap.data_ptr() if rowmap is not None else None
+    d.M, d.N, d.K, d.groups = M, N, K, 1
+    L.check(lib.actmi_op_gemm(C.byref(d), L.current_stream_ptr()), None, "op_gemm")
+    return out
+
+
+def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1, pad=1):
+    """x [G,B,H,W,Cin] camera-major NHWC; w_ohwi [G,Cout,KH,KW,Cin]; scale/bias [G,Cout]; returns [G,B,Ho,Wo,Cout]."""
+    lib = L.load()
+    G, B, H, W, Cin = x.shape
+    _, Cout, KH, KW, _ = w_ohwi.shape
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    out = torch.zeros((G, B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    d = L.GemmDesc()
+    d.A, d.mode = x.data_ptr(), 1
+    d.H, d.W, d.Cin, d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo = H, W, Cin, KH, KW, stride, pad, Ho, Wo
+    d.img_stride = H * W * Cin
+    d.Bw, d.ldb = w_ohwi.data_ptr(), KH * KW * Cin
+    d.scale = scale.data_ptr() if scale is not None else None
+    d.bias = bias.data_ptr() if bias is not None else None
+    if res is not None:
+        d.res, d.ldres = res.data_ptr(), Cout
+    d.relu = 1 if relu else 0
+    d.C, d.ldc = out.data_ptr(), Cout
+    d.M, d.N, d.K, d.groups = B * Ho * Wo, Cout, KH * KW * Cin, G
+    d.gA, d.gB, d.gSB = B * H * W * Cin, Cout * KH * KW * Cin, Cout
+    d.gC = d.gRes = B * Ho * Wo * Cout
+    L.check(lib.actmi_op_gemm(C.byref(d), L.current_stream_ptr()), None, "op_gemm(conv)")
+    return out
+
+
+def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False):
+    """q [B,Nq,D] (or [Nq,D] when q_shared), k/v [B,Nk,D] (views with row stride allowed); returns [B,Nq,D]."""
+    lib = L.load()
+    B, Nk, D = k.shape
+    Nq = q.shape[-2]
+    hd = D // nheads
+    out = torch.zeros((B, Nq, D), dtype=torch.float32, device=k.device)
+    lse = torch.zeros((B, nheads, Nq), dtype=torch.float32, device=k.device) if want_lse else None
+    d = L.AttnDesc()
+    d.Q, d.q_bs, d.q_rs = q.data_ptr(), (0 if q_shared else q.stride(0)), q.stride(-2)
+    d.K, d.k_bs, d.k_rs = k.data_ptr(), k.stride(0), k.stride(1)
+    d.V, d.v_bs, d.v_rs = v.data_ptr(), v.stride(0), v.stride(1)
+    d.O, d.o_bs, d.o_rs = out.data_ptr(), out.stride(0), out.stride(1)
+    if kpm is not None:
+        d.kpm, d.kpm_bs = kpm.data_ptr(), kpm.stride(0)
+    d.lse = lse.data_ptr() if lse is not None else None
+    d.B, d.H, d.Nq, d.Nk, d.HD = B, nheads, Nq, Nk, hd
+    d.scale = 1.0 / (hd ** 0.5)
+    L.check(lib.actmi_op_attention(C.byref(d), L.current_stream_ptr()), None, "op_attention")
+    return (out, lse) if want_lse else out
+
+
+def layernorm(x, w, b, res=None, res_mod=0, w2=None, b2=None, eps=1e-5):
+    lib = L.load()
+    M, D = x.shape
+    y = torch.empty_like(x)
+    L.check(lib.actmi_op_layernorm(_p(x), _p(res), res_mod, _p(w), _p(b), _p(w2), _p(b2), _p(y), M, D, eps,
+                                   L.current_stream_ptr()), None, "op_layernorm")
+    return y
+
+
+def maxpool3x3s2(x):
+    """x [n,H,W,C] NHWC -> [n,Ho,Wo,C]."""
+    lib = L.load()
+    n, H, W, Cc = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((n, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
+    L.check(lib.actmi_op_maxpool3x3s2(_p(x), _p(y), n, H, W, Cc, L.current_stream_ptr()), None, "op_maxpool")
+    return y
+
+
+def conv1(image, w_oihw, scale, bias):
+    """image u8 [B,C,H,W,3] or f32 [B,C,3,H,W]; w [C,Cout,3,7,7]; scale/bias [C,Cout] -> [C,B,Ho,Wo,Cout]."""
+    lib = L.load()
+    image = image.contiguous()
+    if image.dtype == torch.uint8:
+        B, Cn, H, W, _ = image.shape
+        fmt = L.IMG_U8_NHWC
+    else:
+        B, Cn, _, H, W = image.shape
+        fmt = L.IMG_F32_NCHW
+    Cout = w_oihw.shape[1]
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    out = torch.zeros((Cn, B, Ho, Wo, Cout), dtype=torch.float32, device=image.device)
+    ws = torch.empty(Cn * Cout * 148 + 768, dtype=torch.float32, device=image.device)
+    L.check(lib.actmi_op_conv1(_p(image), fmt, _p(w_oihw), _p(scale), _p(bias), _p(out), _p(ws), B, Cn, H, W, Cout,
+                               L.current_stream_ptr()), None, "op_conv1")
+    return out
+
+
+class TemporalEnsemble:
+    """Batched temporal ensembling state for E episodes (reference imitate_episodes.py:338-339, 402-411).
+    Ring buffer [E,Q,Q,A] instead of the reference's [T,T+Q,A] per episode: only the last Q chunks can
+    contribute to step t."""
+
+    def __init__(self, num_episodes, num_queries, action_dim=16, k=0.01, device="cuda:0"):
+        self.E, self.Q, self.A, self.k = num_episodes, num_queries, action_dim, float(k)
+        self.ring = torch.zeros((self.E, self.Q, self.Q, self.A), dtype=torch.float32, device=device)
+        self.t = torch.zeros((self.E,), dtype=torch.int32, device=device)
+        self.out = torch.zeros((self.E, self.A), dtype=torch.float64, device=device)
+        self.populated = torch.zeros((self.E, self.Q), dtype=torch.uint8, device=device)
+
+    def reset(self):
+        self.ring.zero_()
+        self.t.zero_()
+
+    def step(self, all_actions):
+        """all_actions [E,Q,A] f32 cuda -> raw_action [E,A] f64 (same dtype as the reference's raw_action)."""
+        lib = L.load()
+        a = all_actions.contiguous()
+        L.check(lib.actmi_ensemble_step(_p(self.ring), _p(self.t), _p(a), self.k, _p(self.out), _p(self.populated),
+                                        self.E, self.Q, self.A, L.current_stream_ptr()), None, "ensemble_step")
+        return self.out

@@ -1,0 +1,155 @@
+// extern "C" surface of libactmi (declared in include/actmi.h).  Nothing here throws across the boundary.
+#include "engine.h"
+
+#include <cstring>
+
+namespace {
+thread_local std::string g_op_error;
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+int bad(actmi_ctx* h, const std::string& m, int code = ACTMI_E_INVALID) { h->err = m; return code; }
+}  // namespace
+
+extern "C" {
+
+int actmi_version(void) { return ACTMI_VERSION; }
+
+int actmi_create(const actmi_config* cfg, actmi_handle* out) {
+    try {
+        return engine_create(cfg, out);
+    } catch (const std::exception& e) {
+        return ACTMI_E_NOMEM;
+    }
+}
+
+int actmi_destroy(actmi_handle h) { return engine_destroy(h); }
+
+const char* actmi_last_error(actmi_handle h) { return h ? h->err.c_str() : engine_create_error(); }
+
+int actmi_num_params(actmi_handle h) { return h ? (int)h->params.size() : ACTMI_E_INVALID; }
+
+int actmi_param_info(actmi_handle h, int index, const char** key, int64_t* shape4, int* ndim, int* is_buffer) {
+    if (!h || index < 0 || index >= (int)h->params.size()) return ACTMI_E_INVALID;
+    const Param& p = h->params[index];
+    if (key) *key = p.key.c_str();
+    if (ndim) *ndim = (int)p.shape.size();
+    if (shape4) for (size_t i = 0; i < 4; ++i) shape4[i] = i < p.shape.size() ? p.shape[i] : 1;
+    if (is_buffer) *is_buffer = p.is_buffer ? 1 : 0;
+    return 0;
+}
+
+int actmi_set_param(actmi_handle h, const char* key, const void* src, const int64_t* shape, int ndim, int is_device) {
+    if (!h || !key || !src) return ACTMI_E_INVALID;
+    auto it = h->index.find(key);
+    if (it == h->index.end()) return bad(h, std::string("unknown state_dict key: ") + key);
+    const Param& p = h->params[it->second];
+    if (shape) {
+        if (ndim != (int)p.shape.size()) return bad(h, std::string("rank mismatch for ") + key);
+        for (int i = 0; i < ndim; ++i)
+            if (shape[i] != p.shape[i]) return bad(h, std::string("shape mismatch for ") + key);
+    }
+    hipError_t e = hipMemcpy(h->pbase + p.off, src, p.numel * sizeof(float),
+                             is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bad(h, std::string("hipMemcpy: ") + hipGetErrorString(e), ACTMI_E_LAUNCH);
+    h->finalized = false;
+    return 0;
+}
+
+int actmi_get_param(actmi_handle h, const char* key, void* dst, int64_t nbytes, int is_device) {
+    if (!h || !key || !dst) return ACTMI_E_INVALID;
+    auto it = h->index.find(key);
+    if (it == h->index.end()) return bad(h, std::string("unknown state_dict key: ") + key);
+    const Param& p = h->params[it->second];
+    if (nbytes != p.numel * (int64_t)sizeof(float)) return bad(h, std::string("size mismatch for ") + key);
+    hipError_t e = hipMemcpy(dst, h->pbase + p.off, nbytes, is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return bad(h, std::string("hipMemcpy: ") + hipGetErrorString(e), ACTMI_E_LAUNCH);
+    return 0;
+}
+
+int actmi_finalize(actmi_handle h, void* stream) { return h ? engine_finalize(h, S(stream)) : ACTMI_E_INVALID; }
+
+int actmi_forward_infer(actmi_handle h, const float* qpos, const void* image, int image_fmt, int B, float* a_hat,
+                        void* stream) {
+    if (!h) return ACTMI_E_INVALID;
+    if (!qpos || !image || !a_hat) return bad(h, "null pointer");
+    return engine_forward_infer(h, qpos, image, image_fmt, B, a_hat, S(stream));
+}
+
+int actmi_forward_train(actmi_handle h, const float*, const void*, int, const float*, const uint8_t*, const float*,
+                        uint64_t, float, int, float*, float*, float*, float*, void*) {
+    if (!h) return ACTMI_E_INVALID;
+    return bad(h, "training path not built in this version", ACTMI_E_STATE);
+}
+int actmi_backward(actmi_handle h, float, void*) { return h ? bad(h, "training path not built", ACTMI_E_STATE) : ACTMI_E_INVALID; }
+int actmi_zero_grad(actmi_handle h, void*) { return h ? bad(h, "training path not built", ACTMI_E_STATE) : ACTMI_E_INVALID; }
+int actmi_adamw_step(actmi_handle h, float, float, float, float, float, float, int64_t, void*) {
+    return h ? bad(h, "training path not built", ACTMI_E_STATE) : ACTMI_E_INVALID;
+}
+int actmi_grad_ptr(actmi_handle h, const char*, void**, int64_t*) {
+    return h ? bad(h, "training path not built", ACTMI_E_STATE) : ACTMI_E_INVALID;
+}
+
+int actmi_ensemble_step(float* ring, int32_t* tcount, const float* chunk, double k, double* out, uint8_t* populated, int E,
+                        int Q, int A, void* stream) {
+    if (!ring || !tcount || !chunk || !out || Q < 1 || A < 1 || A > 64) return ACTMI_E_INVALID;
+    return launch_ensemble(ring, tcount, chunk, k, out, populated, E, Q, A, S(stream));
+}
+
+int actmi_op_gemm(const actmi_gemm_desc* d, void* stream) {
+    if (!d) return ACTMI_E_INVALID;
+    g_op_error.clear();
+    return launch_gemm(*d, S(stream), &g_op_error);
+}
+
+int actmi_op_attention(const actmi_attn_desc* d, void* stream) {
+    if (!d) return ACTMI_E_INVALID;
+    g_op_error.clear();
+    return launch_attention(*d, S(stream), &g_op_error);
+}
+
+int actmi_op_layernorm(const float* x, const float* res, int res_mod, const float* w, const float* b, const float* w2,
+                       const float* b2, float* y, int M, int D, float eps, void* stream) {
+    g_op_error.clear();
+    return launch_layernorm(x, res, res_mod, w, b, w2, b2, y, M, D, eps, S(stream), &g_op_error);
+}
+
+int actmi_op_maxpool3x3s2(const float* in, float* out, int nimg, int H, int W, int C, void* stream) {
+    return launch_maxpool(in, out, nimg, H, W, C, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, S(stream));
+}
+
+int actmi_op_conv1(const void* image, int image_fmt, const float* w_oihw, const float* scale, const float* bias,
+                   float* out, float* workspace, int B, int C, int H, int W, int Cout, void* stream) {
+    g_op_error.clear();
+    float* wp = workspace;
+    float* lut = workspace + (int64_t)C * Cout * 148;
+    int rc = launch_repack_conv_w(w_oihw, wp, C, Cout, 3, 7, 7, (int64_t)Cout * 147, (int64_t)Cout * 148, 148, S(stream));
+    if (rc) return rc;
+    float hl[768];
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int c = 0; c < 3; ++c)
+        for (int v = 0; v < 256; ++v) hl[c * 256 + v] = ((float)((double)v / 255.0) - mean[c]) / stdv[c];
+    if (hipMemcpyAsync(lut, hl, sizeof(hl), hipMemcpyHostToDevice, S(stream)) != hipSuccess) return ACTMI_E_LAUNCH;
+    if (hipStreamSynchronize(S(stream)) != hipSuccess) return ACTMI_E_LAUNCH;
+    Conv1Args a;
+    a.image = image; a.fmt = image_fmt; a.lut = lut; a.w = wp; a.scale = scale; a.bias = bias; a.out = out;
+    a.B = B; a.C = C; a.H = H; a.W = W; a.Ho = (H + 6 - 7) / 2 + 1; a.Wo = (W + 6 - 7) / 2 + 1; a.Cout = Cout;
+    return launch_conv1(a, S(stream), &g_op_error);
+}
+
+const char* actmi_op_last_error(void) { return g_op_error.c_str(); }
+
+int actmi_debug_stop_after(actmi_handle h, const char* stage) {
+    if (!h) return ACTMI_E_INVALID;
+    h->stop_stage = stage ? stage : "";
+    return 0;
+}
+
+int actmi_debug_tensor(actmi_handle h, const char* name, const float** dev_ptr, int64_t* numel) {
+    if (!h || !name) return ACTMI_E_INVALID;
+    auto it = h->dbg.find(name);
+    if (it == h->dbg.end()) return bad(h, std::string("no debug tensor ") + name);
+    if (dev_ptr) *dev_ptr = it->second.ptr;
+    if (numel) *numel = it->second.numel;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// Shared declarations for libactmi (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "actmi.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define ACTMI_WAVE 64
+
+struct ActmiError {
+    int code;
+    std::string msg;
+};
+
+// ---- GEMM / implicit-GEMM convolution (gemm.hip): descriptor is part of the C ABI (include/actmi.h)
+typedef actmi_gemm_desc GemmArgs;
+
+int launch_gemm(const GemmArgs& a, hipStream_t st, std::string* err);
+
+// ---- conv1 7x7/s2 + FrozenBN + ReLU (conv1.hip) -----------------------------------------------
+struct Conv1Args {
+    const void* image;    // u8 NHWC [B][C][H][W][3] or f32 NCHW [B][C][3][H][W]
+    int fmt;              // 0 = U8_NHWC, 1 = F32_NCHW
+    const float* lut;     // [3][256] normalised values for u8 input
+    const float* w;       // [C][Cout][KPAD] (r,s,c) order, zero padded
+    const float* scale;   // [C][Cout]
+    const float* bias;    // [C][Cout]
+    float* out;           // camera-major NHWC [C][B][Ho][Wo][Cout]
+    int B, C, H, W, Ho, Wo, Cout;
+};
+int launch_conv1(const Conv1Args& a, hipStream_t st, std::string* err);
+
+// ---- 3x3/s2/p1 max pool NHWC (pool.hip) -----------------------------------------------------
+int launch_maxpool(const float* in, float* out, int nimg, int H, int W, int C, int Ho, int Wo, hipStream_t st);
+
+// ---- LayerNorm (layernorm.hip) ----------------------------------------------------------------
+// y = LN(x + res[m % res_mod]) * w + b ; optional second LN (w2,b2) applied on top.
+int launch_layernorm(const float* x, const float* res, int res_mod, const float* w, const float* b,
+                     const float* w2, const float* b2, float* y, int M, int D, float eps, hipStream_t st,
+                     std::string* err);
+
+// ---- attention (attn.hip) -----------------------------------------------------------------------
+typedef actmi_attn_desc AttnArgs;
+int launch_attention(const AttnArgs& a, hipStream_t st, std::string* err);
+
+// ---- small kernels (misc.hip) --------------------------------------------------------------------
+int launch_small_linear(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
+                        int M, int N, int K, hipStream_t st);
+int launch_fill_rows(float* dst, int64_t ld, int64_t batch_stride, const float* src, int64_t src_bs, int B, int D,
+                     hipStream_t st);
+int launch_repack_conv_w(const float* w_oihw, float* w_ohwi, int G, int O, int I, int KH, int KW, int64_t g_in,
+                         int64_t g_out, int kpad, hipStream_t st);
+int launch_ensemble(float* ring, int* tcount, const float* chunk, double k, double* out, uint8_t* populated, int E,
+                    int Q, int A, hipStream_t st);
+int launch_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale, float* bias, int n,
+                   hipStream_t st);
+int launch_build_rowmap(int* map, int B, int C, int fh, int fw, int N, hipStream_t st);

@@ -1,0 +1,550 @@
+// Host side of libactmi: parameter store in the reference's state_dict layout, weight preparation, and the
+// inference graph of one ACT policy query (reference detr_vae.py:163-254,
+// transformer.py:49-122, 211-224, 274-295).  No allocation and no host synchronisation on the forward path:
+// every buffer is sized for cfg.max_batch at create time and all work is enqueued on the caller's stream,
+// so the whole forward can be captured in a hipGraph by the caller.
+#include "engine.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+#define HIPCHK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+            return ACTMI_E_LAUNCH;                                                              \
+        }                                                                                       \
+    } while (0)
+
+#define CHK(expr)                                                                               \
+    do {                                                                                        \
+        int _rc = (expr);                                                                       \
+        if (_rc != 0) {                                                                         \
+            if (ctx->err.empty()) ctx->err = std::string("failed: ") + #expr;                   \
+            return _rc < -5 ? ACTMI_E_LAUNCH : _rc;                                             \
+        }                                                                                       \
+    } while (0)
+
+int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
+
+void add_param(actmi_ctx* c, const std::string& key, std::vector<int64_t> shape, bool is_buffer) {
+    Param p;
+    p.key = key;
+    p.shape = shape;
+    p.numel = 1;
+    for (auto d : shape) p.numel *= d;
+    p.off = c->ptotal;
+    p.is_buffer = is_buffer;
+    c->ptotal += (p.numel + 63) & ~int64_t(63);   // 256-byte aligned slots
+    c->index[key] = (int)c->params.size();
+    c->params.push_back(p);
+}
+
+void add_mha(actmi_ctx* c, const std::string& p, int D) {
+    add_param(c, p + "in_proj_weight", {3 * D, D}, false);
+    add_param(c, p + "in_proj_bias", {3 * D}, false);
+    add_param(c, p + "out_proj.weight", {D, D}, false);
+    add_param(c, p + "out_proj.bias", {D}, false);
+}
+
+void add_ffn_norms(actmi_ctx* c, const std::string& p, int D, int F, int nnorm) {
+    add_param(c, p + "linear1.weight", {F, D}, false);
+    add_param(c, p + "linear1.bias", {F}, false);
+    add_param(c, p + "linear2.weight", {D, F}, false);
+    add_param(c, p + "linear2.bias", {D}, false);
+    for (int i = 1; i <= nnorm; ++i) {
+        add_param(c, p + "norm" + std::to_string(i) + ".weight", {D}, false);
+        add_param(c, p + "norm" + std::to_string(i) + ".bias", {D}, false);
+    }
+}
+
+void add_fbn(actmi_ctx* c, const std::string& p, int n) {
+    for (const char* s : {"weight", "bias", "running_mean", "running_var"}) add_param(c, p + s, {n}, true);
+}
+
+// state_dict spec in the registration order of the reference (detr_vae.py:49-105); mirrors actmi/weights.py
+void build_spec(actmi_ctx* c) {
+    const actmi_config& g = c->cfg;
+    const int D = g.hidden_dim, F = g.dim_feedforward, Q = g.num_queries, S = g.state_dim, A = g.action_dim,
+              L = g.latent_dim, w0 = g.base_width;
+    add_param(c, "pos_table", {1, Q + 2, D}, true);
+    for (int i = 0; i < g.enc_layers; ++i) {
+        std::string p = "transformer.encoder.layers." + std::to_string(i) + ".";
+        add_mha(c, p + "self_attn.", D);
+        add_ffn_norms(c, p, D, F, 2);
+    }
+    for (int i = 0; i < g.dec_layers; ++i) {
+        std::string p = "transformer.decoder.layers." + std::to_string(i) + ".";
+        add_mha(c, p + "self_attn.", D);
+        add_mha(c, p + "multihead_attn.", D);
+        add_ffn_norms(c, p, D, F, 3);
+    }
+    add_param(c, "transformer.decoder.norm.weight", {D}, false);
+    add_param(c, "transformer.decoder.norm.bias", {D}, false);
+    if (g.has_cvae_encoder) {
+        for (int i = 0; i < g.enc_layers; ++i) {
+            std::string p = "encoder.layers." + std::to_string(i) + ".";
+            add_mha(c, p + "self_attn.", D);
+            add_ffn_norms(c, p, D, F, 2);
+        }
+    }
+    add_param(c, "action_head.weight", {A, D}, false);
+    add_param(c, "action_head.bias", {A}, false);
+    add_param(c, "is_pad_head.weight", {1, D}, false);
+    add_param(c, "is_pad_head.bias", {1}, false);
+    add_param(c, "query_embed.weight", {Q, D}, false);
+    add_param(c, "input_proj.weight", {D, 8 * w0, 1, 1}, false);
+    add_param(c, "input_proj.bias", {D}, false);
+    for (int cam = 0; cam < g.num_cams; ++cam) {
+        std::string p = "backbones." + std::to_string(cam) + ".0.body.";
+        add_param(c, p + "conv1.weight", {w0, 3, 7, 7}, false);
+        add_fbn(c, p + "bn1.", w0);
+        int cin = w0;
+        for (int li = 1; li <= 4; ++li) {
+            const int cout = w0 << (li - 1);
+            for (int bi = 0; bi < 2; ++bi) {
+                std::string bp = p + "layer" + std::to_string(li) + "." + std::to_string(bi) + ".";
+                add_param(c, bp + "conv1.weight", {cout, cin, 3, 3}, false);
+                add_fbn(c, bp + "bn1.", cout);
+                add_param(c, bp + "conv2.weight", {cout, cout, 3, 3}, false);
+                add_fbn(c, bp + "bn2.", cout);
+                if (bi == 0 && li > 1) {
+                    add_param(c, bp + "downsample.0.weight", {cout, cin, 1, 1}, false);
+                    add_fbn(c, bp + "downsample.1.", cout);
+                }
+                cin = cout;
+            }
+        }
+    }
+    add_param(c, "input_proj_robot_state.weight", {D, S}, false);
+    add_param(c, "input_proj_robot_state.bias", {D}, false);
+    add_param(c, "cls_embed.weight", {1, D}, false);
+    add_param(c, "encoder_action_proj.weight", {D, A}, false);
+    add_param(c, "encoder_action_proj.bias", {D}, false);
+    add_param(c, "encoder_joint_proj.weight", {D, S}, false);
+    add_param(c, "encoder_joint_proj.bias", {D}, false);
+    add_param(c, "latent_proj.weight", {2 * L, D}, false);
+    add_param(c, "latent_proj.bias", {2 * L}, false);
+    add_param(c, "latent_out_proj.weight", {D, L}, false);
+    add_param(c, "latent_out_proj.bias", {D}, false);
+    add_param(c, "additional_pos_embed.weight", {2, D}, false);
+}
+
+int dev_alloc(actmi_ctx* ctx, float** p, int64_t nfloats) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, (size_t)(nfloats > 0 ? nfloats : 1) * sizeof(float));
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return ACTMI_E_NOMEM;
+    }
+    ctx->allocs.push_back(q);
+    *p = reinterpret_cast<float*>(q);
+    return 0;
+}
+
+MhaW mha_w(actmi_ctx* c, const std::string& p) {
+    MhaW m;
+    m.in_w = c->P(p + "in_proj_weight");
+    m.in_b = c->P(p + "in_proj_bias");
+    m.out_w = c->P(p + "out_proj.weight");
+    m.out_b = c->P(p + "out_proj.bias");
+    return m;
+}
+
+void resolve_layers(actmi_ctx* c) {
+    const actmi_config& g = c->cfg;
+    auto enc = [&](const std::string& p) {
+        EncW e;
+        e.attn = mha_w(c, p + "self_attn.");
+        e.l1w = c->P(p + "linear1.weight"); e.l1b = c->P(p + "linear1.bias");
+        e.l2w = c->P(p + "linear2.weight"); e.l2b = c->P(p + "linear2.bias");
+        e.n1w = c->P(p + "norm1.weight"); e.n1b = c->P(p + "norm1.bias");
+        e.n2w = c->P(p + "norm2.weight"); e.n2b = c->P(p + "norm2.bias");
+        return e;
+    };
+    c->enc.clear(); c->cvae.clear(); c->dec.clear();
+    for (int i = 0; i < g.enc_layers; ++i) c->enc.push_back(enc("transformer.encoder.layers." + std::to_string(i) + "."));
+    if (g.has_cvae_encoder)
+        for (int i = 0; i < g.enc_layers; ++i) c->cvae.push_back(enc("encoder.layers." + std::to_string(i) + "."));
+    for (int i = 0; i < g.dec_layers; ++i) {
+        std::string p = "transformer.decoder.layers." + std::to_string(i) + ".";
+        DecW d;
+        d.self_attn = mha_w(c, p + "self_attn.");
+        d.cross = mha_w(c, p + "multihead_attn.");
+        d.l1w = c->P(p + "linear1.weight"); d.l1b = c->P(p + "linear1.bias");
+        d.l2w = c->P(p + "linear2.weight"); d.l2b = c->P(p + "linear2.bias");
+        d.n1w = c->P(p + "norm1.weight"); d.n1b = c->P(p + "norm1.bias");
+        d.n2w = c->P(p + "norm2.weight"); d.n2b = c->P(p + "norm2.bias");
+        d.n3w = c->P(p + "norm3.weight"); d.n3b = c->P(p + "norm3.bias");
+        c->dec.push_back(d);
+    }
+}
+
+GemmArgs linear_args(const float* A, int64_t lda, int M, int K, const float* W, int N, const float* bias, float* C,
+                     int64_t ldc) {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.M = M; a.K = K; a.N = N; a.Bw = W; a.ldb = K; a.bias = bias; a.C = C; a.ldc = ldc;
+    a.groups = 1;
+    return a;
+}
+
+}  // namespace
+
+float* actmi_ctx::P(const std::string& key) {
+    auto it = index.find(key);
+    if (it == index.end()) return nullptr;
+    return pbase + params[it->second].off;
+}
+
+// ------------------------------------------------------------------------------------------------
+// create / destroy
+// ------------------------------------------------------------------------------------------------
+
+int engine_create(const actmi_config* cfg, actmi_ctx** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return ACTMI_E_INVALID; }
+    const actmi_config& g = *cfg;
+    if (g.num_cams < 1 || g.max_batch < 1 || g.hidden_dim % g.nheads || (g.hidden_dim & 3) || (g.dim_feedforward & 3) ||
+        (g.base_width & 3) || g.base_width > 64 || g.enc_layers < 1 || g.dec_layers < 1) {
+        g_create_error = "unsupported configuration";
+        return ACTMI_E_INVALID;
+    }
+    const int hd = g.hidden_dim / g.nheads;
+    if (hd != 16 && hd != 32 && hd != 64) { g_create_error = "head_dim must be 16, 32 or 64"; return ACTMI_E_INVALID; }
+    actmi_ctx* ctx = new actmi_ctx();
+    ctx->cfg = g;
+    ctx->ptotal = 0;
+    build_spec(ctx);
+    // geometry
+    ctx->H1 = conv_out(g.image_h, 7, 2, 3); ctx->W1 = conv_out(g.image_w, 7, 2, 3);
+    ctx->H2 = conv_out(ctx->H1, 3, 2, 1); ctx->W2 = conv_out(ctx->W1, 3, 2, 1);
+    int h = ctx->H2, w = ctx->W2;
+    for (int i = 0; i < 3; ++i) { h = conv_out(h, 3, 2, 1); w = conv_out(w, 3, 2, 1); }
+    ctx->fh = h; ctx->fw = w;
+    ctx->P_ = h * w;
+    ctx->N = 2 + g.num_cams * h * w;
+    if (h < 1 || w < 1) { g_create_error = "image too small"; delete ctx; return ACTMI_E_INVALID; }
+
+    auto fail = [&](int rc) { g_create_error = ctx->err; engine_destroy(ctx); return rc; };
+    int rc;
+    if ((rc = dev_alloc(ctx, &ctx->pbase, ctx->ptotal))) return fail(rc);
+    if (hipMemset(ctx->pbase, 0, ctx->ptotal * sizeof(float)) != hipSuccess) { ctx->err = "hipMemset failed"; return fail(ACTMI_E_LAUNCH); }
+    resolve_layers(ctx);
+
+    // ---- conv layer table + packed weights
+    const int C = g.num_cams, w0 = g.base_width;
+    {
+        int cin = w0, H = ctx->H2, W = ctx->W2;
+        for (int li = 1; li <= 4; ++li) {
+            const int cout = w0 << (li - 1);
+            for (int bi = 0; bi < 2; ++bi) {
+                const int s = (bi == 0 && li > 1) ? 2 : 1;
+                std::string bp = "layer" + std::to_string(li) + "." + std::to_string(bi) + ".";
+                ConvLayer c1{bp + "conv1", bp + "bn1.", cin, cout, 3, s, 1, H, W, conv_out(H, 3, s, 1), conv_out(W, 3, s, 1)};
+                ConvLayer c2{bp + "conv2", bp + "bn2.", cout, cout, 3, 1, 1, c1.Ho, c1.Wo, c1.Ho, c1.Wo};
+                ctx->convs.push_back(c1);
+                ctx->convs.push_back(c2);
+                if (bi == 0 && li > 1) {
+                    ConvLayer ds{bp + "downsample.0", bp + "downsample.1.", cin, cout, 1, s, 0, H, W, c1.Ho, c1.Wo};
+                    ctx->convs.push_back(ds);
+                }
+                cin = cout; H = c1.Ho; W = c1.Wo;
+            }
+        }
+        for (auto& cl : ctx->convs) {
+            cl.K = cl.k * cl.k * cl.cin;
+            if ((rc = dev_alloc(ctx, &cl.w, (int64_t)C * cl.cout * cl.K))) return fail(rc);
+            if ((rc = dev_alloc(ctx, &cl.scale, (int64_t)C * cl.cout))) return fail(rc);
+            if ((rc = dev_alloc(ctx, &cl.bias, (int64_t)C * cl.cout))) return fail(rc);
+        }
+    }
+    const int D = g.hidden_dim, F = g.dim_feedforward, Q = g.num_queries, N = ctx->N, B = g.max_batch;
+    if ((rc = dev_alloc(ctx, &ctx->conv1_w, (int64_t)C * w0 * 148))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->conv1_scale, (int64_t)C * w0))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->conv1_bias, (int64_t)C * w0))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->lut, 768))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->pos_tokens, (int64_t)N * D))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->dec_t1, D))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->dec_q, (int64_t)Q * D))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->tmp_vec, 4 * D))) return fail(rc);
+    {
+        float* rm = nullptr;
+        if ((rc = dev_alloc(ctx, &rm, (int64_t)B * C * ctx->P_))) return fail(rc);
+        ctx->rowmap = reinterpret_cast<int*>(rm);
+        ctx->rowmap_B = -1;
+    }
+    // ---- activations (camera-major NHWC maps, token-major [B][N][D])
+    const int64_t n1 = (int64_t)C * B * ctx->H1 * ctx->W1 * w0;
+    const int64_t n2 = (int64_t)C * B * ctx->H2 * ctx->W2 * w0;
+    if ((rc = dev_alloc(ctx, &ctx->act1, n1))) return fail(rc);
+    for (int i = 0; i < 3; ++i)
+        if ((rc = dev_alloc(ctx, &ctx->buf[i], n2))) return fail(rc);
+    const int64_t BN_ = (int64_t)B * N;
+    if ((rc = dev_alloc(ctx, &ctx->X, BN_ * D))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->X1, BN_ * D))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->Y, BN_ * D))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->ATT, BN_ * D))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->QKV, BN_ * 3 * D))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->Hb, BN_ * F))) return fail(rc);
+    const int64_t BQ = (int64_t)B * Q;
+    if ((rc = dev_alloc(ctx, &ctx->dO, BQ * D))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->dY, BQ * D))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->dT2, BQ * D))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->dH, BQ * F))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->hs, BQ * D))) return fail(rc);
+    ctx->finalized = false;
+    *out = ctx;
+    return 0;
+}
+
+int engine_destroy(actmi_ctx* ctx) {
+    if (!ctx) return 0;
+    for (void* p : ctx->allocs) (void)hipFree(p);
+    delete ctx;
+    return 0;
+}
+
+const char* engine_create_error() { return g_create_error.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+// finalize: weight preparation
+// ------------------------------------------------------------------------------------------------
+
+int engine_finalize(actmi_ctx* ctx, hipStream_t st) {
+    ctx->err.clear();
+    const actmi_config& g = ctx->cfg;
+    const int C = g.num_cams, w0 = g.base_width, D = g.hidden_dim, Q = g.num_queries;
+    // 1. conv weights OIHW -> [cam][O][(r,s,c)], FrozenBN -> scale/bias
+    for (int cam = 0; cam < C; ++cam) {
+        std::string p = "backbones." + std::to_string(cam) + ".0.body.";
+        CHK(launch_repack_conv_w(ctx->P(p + "conv1.weight"), ctx->conv1_w + (int64_t)cam * w0 * 148, 1, w0, 3, 7, 7, 0, 0,
+                                 148, st));
+        CHK(launch_bn_fold(ctx->P(p + "bn1.weight"), ctx->P(p + "bn1.bias"), ctx->P(p + "bn1.running_mean"),
+                           ctx->P(p + "bn1.running_var"), ctx->conv1_scale + cam * w0, ctx->conv1_bias + cam * w0, w0, st));
+        for (auto& cl : ctx->convs) {
+            CHK(launch_repack_conv_w(ctx->P(p + cl.name + ".weight"), cl.w + (int64_t)cam * cl.cout * cl.K, 1, cl.cout,
+                                     cl.cin, cl.k, cl.k, 0, 0, cl.K, st));
+            CHK(launch_bn_fold(ctx->P(p + cl.bn + "weight"), ctx->P(p + cl.bn + "bias"), ctx->P(p + cl.bn + "running_mean"),
+                               ctx->P(p + cl.bn + "running_var"), cl.scale + cam * cl.cout, cl.bias + cam * cl.cout,
+                               cl.cout, st));
+        }
+    }
+    // 2. u8 -> normalised float LUT with the reference's arithmetic:
+    //    x = float(v / 255.0 in f64)  (imitate_episodes.py:212), (x - mean) / std in f32 (policy.py:268-272)
+    {
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+        std::vector<float> lut(768);
+        for (int c = 0; c < 3; ++c)
+            for (int v = 0; v < 256; ++v) {
+                const float x = (float)((double)v / 255.0);
+                lut[c * 256 + v] = (x - mean[c]) / stdv[c];
+            }
+        HIPCHK(hipMemcpyAsync(ctx->lut, lut.data(), 768 * sizeof(float), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    // 3. position table per token: rows 0,1 = additional_pos_embed (transformer.py:91-92); rows 2.. =
+    //    PositionEmbeddingSine(normalize=True) (position_encoding.py:30-52), identical for every camera
+    {
+        const int fh = ctx->fh, fw = ctx->fw, N = ctx->N, npf = D / 2;
+        std::vector<float> pos((size_t)N * D, 0.f);
+        HIPCHK(hipMemcpy(pos.data(), ctx->P("additional_pos_embed.weight"), 2 * D * sizeof(float), hipMemcpyDeviceToHost));
+        const float eps = 1e-6f, scale = (float)(2.0 * M_PI);
+        std::vector<float> dim_t(npf);
+        for (int k = 0; k < npf; ++k) dim_t[k] = powf(10000.f, (2.f * (float)(k / 2)) / (float)npf);
+        for (int hh = 0; hh < fh; ++hh)
+            for (int cam = 0; cam < C; ++cam)
+                for (int ww = 0; ww < fw; ++ww) {
+                    float* row = &pos[(size_t)(2 + hh * (fw * C) + cam * fw + ww) * D];
+                    const float y = (float)(hh + 1) / ((float)fh + eps) * scale;
+                    const float x = (float)(ww + 1) / ((float)fw + eps) * scale;
+                    for (int k = 0; k < npf; ++k) {
+                        const float py = y / dim_t[k], px = x / dim_t[k];
+                        row[k] = (k & 1) ? cosf(py) : sinf(py);
+                        row[npf + k] = (k & 1) ? cosf(px) : sinf(px);
+                    }
+                }
+        HIPCHK(hipMemcpy(ctx->pos_tokens, pos.data(), pos.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // 4. decoder layer 0, constant part: tgt = 0 => self-attention output is
+    //    out_proj(b_v) + b_o for every query; t1 = norm1 of it; q = (t1 + query_embed) Wq^T + bq.
+    {
+        const DecW& d = ctx->dec[0];
+        GemmArgs a = linear_args(d.self_attn.in_b + 2 * D, D, 1, D, d.self_attn.out_w, D, d.self_attn.out_b, ctx->tmp_vec, D);
+        CHK(launch_gemm(a, st, &ctx->err));
+        CHK(launch_layernorm(ctx->tmp_vec, nullptr, 0, d.n1w, d.n1b, nullptr, nullptr, ctx->dec_t1, 1, D, 1e-5f, st, &ctx->err));
+        GemmArgs q = linear_args(ctx->P("query_embed.weight"), D, Q, D, d.cross.in_w, D, d.cross.in_b, ctx->dec_q, D);
+        q.A_add = ctx->dec_t1; q.ld_add = D; q.add_mod = 1; q.add_ncols = D;
+        CHK(launch_gemm(q, st, &ctx->err));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    ctx->finalized = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward pieces
+// ------------------------------------------------------------------------------------------------
+
+// multi-camera ResNet18 trunk + input_proj -> token rows 2.. of X   (backbone.py:66-71, detr_vae.py:180-185)
+int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream_t st) {
+    const actmi_config& g = ctx->cfg;
+    const int C = g.num_cams, w0 = g.base_width, D = g.hidden_dim;
+    Conv1Args c1;
+    c1.image = image; c1.fmt = fmt; c1.lut = ctx->lut; c1.w = ctx->conv1_w; c1.scale = ctx->conv1_scale;
+    c1.bias = ctx->conv1_bias; c1.out = ctx->act1; c1.B = B; c1.C = C; c1.H = g.image_h; c1.W = g.image_w;
+    c1.Ho = ctx->H1; c1.Wo = ctx->W1; c1.Cout = w0;
+    CHK(launch_conv1(c1, st, &ctx->err));
+    CHK(launch_maxpool(ctx->act1, ctx->buf[0], C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
+    float* cur = ctx->buf[0];
+    float* s1 = ctx->buf[1];
+    float* s2 = ctx->buf[2];
+    ctx->dbg.clear();
+    ctx->dbg["conv1"] = {ctx->act1, (int64_t)C * B * ctx->H1 * ctx->W1 * w0};
+    ctx->dbg["maxpool"] = {cur, (int64_t)C * B * ctx->H2 * ctx->W2 * w0};
+    if (ctx->stop_stage == "conv1" || ctx->stop_stage == "maxpool") return 1;
+    auto run_conv = [&](const ConvLayer& cl, const float* in, float* out, const float* res, int relu) -> int {
+        GemmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.mode = 1;
+        a.A = in; a.H = cl.H; a.W = cl.W; a.Cin = cl.cin; a.KH = a.KW = cl.k; a.stride = cl.stride; a.pad = cl.pad;
+        a.Ho = cl.Ho; a.Wo = cl.Wo; a.img_stride = (int64_t)cl.H * cl.W * cl.cin;
+        a.M = B * cl.Ho * cl.Wo; a.N = cl.cout; a.K = cl.K;
+        a.Bw = cl.w; a.ldb = cl.K; a.scale = cl.scale; a.bias = cl.bias; a.res = res; a.ldres = cl.cout; a.relu = relu;
+        a.C = out; a.ldc = cl.cout;
+        a.groups = C;
+        a.gA = (int64_t)B * cl.H * cl.W * cl.cin; a.gB = (int64_t)cl.cout * cl.K; a.gSB = cl.cout;
+        a.gC = (int64_t)a.M * cl.cout; a.gRes = a.gC;
+        return launch_gemm(a, st, &ctx->err);
+    };
+    size_t ci = 0;
+    for (int li = 1; li <= 4; ++li) {
+        for (int bi = 0; bi < 2; ++bi) {
+            const ConvLayer& k1 = ctx->convs[ci++];
+            const ConvLayer& k2 = ctx->convs[ci++];
+            const bool has_ds = (bi == 0 && li > 1);
+            CHK(run_conv(k1, cur, s1, nullptr, 1));
+            if (has_ds) {
+                const ConvLayer& ds = ctx->convs[ci++];
+                CHK(run_conv(ds, cur, s2, nullptr, 0));
+                CHK(run_conv(k2, s1, cur, s2, 1));       // x is dead: reuse its buffer for the block output
+            } else {
+                CHK(run_conv(k2, s1, s2, cur, 1));
+                std::swap(cur, s2);
+            }
+            if (bi == 1) {
+                const std::string nm = "layer" + std::to_string(li);
+                ctx->dbg[nm] = {cur, (int64_t)C * B * k2.Ho * k2.Wo * k2.cout};
+                if (ctx->stop_stage == nm) return 1;    // debug early-out: buffers rotate, views alias
+            }
+        }
+    }
+    if (ctx->rowmap_B != B) {
+        CHK(launch_build_rowmap(ctx->rowmap, B, C, ctx->fh, ctx->fw, ctx->N, st));
+        ctx->rowmap_B = B;
+    }
+    GemmArgs ip = linear_args(cur, 8 * w0, C * B * ctx->P_, 8 * w0, ctx->P("input_proj.weight"), D,
+                              ctx->P("input_proj.bias"), ctx->X, D);
+    ip.rowmap = ctx->rowmap;
+    CHK(launch_gemm(ip, st, &ctx->err));
+    return 0;
+}
+
+// one post-norm encoder layer on x [B*n][D] in place (transformer.py:211-224)
+int engine_encoder_layer(actmi_ctx* ctx, const EncW& w, float* x, const float* pos, int B, int n, const uint8_t* kpm,
+                         hipStream_t st) {
+    const actmi_config& g = ctx->cfg;
+    const int D = g.hidden_dim, F = g.dim_feedforward, M = B * n, hd = D / g.nheads;
+    GemmArgs qkv = linear_args(x, D, M, D, w.attn.in_w, 3 * D, w.attn.in_b, ctx->QKV, 3 * D);
+    qkv.A_add = pos; qkv.ld_add = D; qkv.add_mod = n; qkv.add_ncols = 2 * D;     // q = k = x + pos, v = x
+    CHK(launch_gemm(qkv, st, &ctx->err));
+    AttnArgs at;
+    memset(&at, 0, sizeof(at));
+    at.Q = ctx->QKV; at.q_bs = (int64_t)n * 3 * D; at.q_rs = 3 * D;
+    at.K = ctx->QKV + D; at.k_bs = at.q_bs; at.k_rs = 3 * D;
+    at.V = ctx->QKV + 2 * D; at.v_bs = at.q_bs; at.v_rs = 3 * D;
+    at.O = ctx->ATT; at.o_bs = (int64_t)n * D; at.o_rs = D;
+    at.kpm = kpm; at.kpm_bs = n;
+    at.B = B; at.H = g.nheads; at.Nq = n; at.Nk = n; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
+    CHK(launch_attention(at, st, &ctx->err));
+    GemmArgs op = linear_args(ctx->ATT, D, M, D, w.attn.out_w, D, w.attn.out_b, ctx->Y, D);
+    op.res = x; op.ldres = D;
+    CHK(launch_gemm(op, st, &ctx->err));
+    CHK(launch_layernorm(ctx->Y, nullptr, 0, w.n1w, w.n1b, nullptr, nullptr, ctx->X1, M, D, 1e-5f, st, &ctx->err));
+    GemmArgs f1 = linear_args(ctx->X1, D, M, D, w.l1w, F, w.l1b, ctx->Hb, F);
+    f1.relu = 1;
+    CHK(launch_gemm(f1, st, &ctx->err));
+    GemmArgs f2 = linear_args(ctx->Hb, F, M, F, w.l2w, D, w.l2b, ctx->Y, D);
+    f2.res = ctx->X1; f2.ldres = D;
+    CHK(launch_gemm(f2, st, &ctx->err));
+    CHK(launch_layernorm(ctx->Y, nullptr, 0, w.n2w, w.n2b, nullptr, nullptr, x, M, D, 1e-5f, st, &ctx->err));
+    return 0;
+}
+
+// decoder layer 0 with the constant query path + heads (transformer.py:274-295,175; detr_vae.py:245,252)
+int engine_decoder_infer(actmi_ctx* ctx, int B, float* a_hat, hipStream_t st) {
+    const actmi_config& g = ctx->cfg;
+    const int D = g.hidden_dim, F = g.dim_feedforward, Q = g.num_queries, N = ctx->N, hd = D / g.nheads;
+    const DecW& d = ctx->dec[0];
+    float* KV = ctx->QKV;   // [B*N][2D]
+    GemmArgs kv = linear_args(ctx->X, D, B * N, D, d.cross.in_w + (int64_t)D * D, 2 * D, d.cross.in_b + D, KV, 2 * D);
+    kv.A_add = ctx->pos_tokens; kv.ld_add = D; kv.add_mod = N; kv.add_ncols = D;      // k = memory + pos, v = memory
+    CHK(launch_gemm(kv, st, &ctx->err));
+    AttnArgs at;
+    memset(&at, 0, sizeof(at));
+    at.Q = ctx->dec_q; at.q_bs = 0; at.q_rs = D;
+    at.K = KV; at.k_bs = (int64_t)N * 2 * D; at.k_rs = 2 * D;
+    at.V = KV + D; at.v_bs = at.k_bs; at.v_rs = 2 * D;
+    at.O = ctx->dO; at.o_bs = (int64_t)Q * D; at.o_rs = D;
+    at.B = B; at.H = g.nheads; at.Nq = Q; at.Nk = N; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
+    CHK(launch_attention(at, st, &ctx->err));
+    const int M = B * Q;
+    GemmArgs op = linear_args(ctx->dO, D, M, D, d.cross.out_w, D, d.cross.out_b, ctx->dY, D);
+    op.res = ctx->dec_t1; op.ldres = D; op.res_mod = 1;
+    CHK(launch_gemm(op, st, &ctx->err));
+    CHK(launch_layernorm(ctx->dY, nullptr, 0, d.n2w, d.n2b, nullptr, nullptr, ctx->dT2, M, D, 1e-5f, st, &ctx->err));
+    GemmArgs f1 = linear_args(ctx->dT2, D, M, D, d.l1w, F, d.l1b, ctx->dH, F);
+    f1.relu = 1;
+    CHK(launch_gemm(f1, st, &ctx->err));
+    GemmArgs f2 = linear_args(ctx->dH, F, M, F, d.l2w, D, d.l2b, ctx->dY, D);
+    f2.res = ctx->dT2; f2.ldres = D;
+    CHK(launch_gemm(f2, st, &ctx->err));
+    CHK(launch_layernorm(ctx->dY, nullptr, 0, d.n3w, d.n3b, ctx->P("transformer.decoder.norm.weight"),
+                         ctx->P("transformer.decoder.norm.bias"), ctx->hs, M, D, 1e-5f, st, &ctx->err));
+    GemmArgs ah = linear_args(ctx->hs, D, M, D, ctx->P("action_head.weight"), g.action_dim, ctx->P("action_head.bias"),
+                              a_hat, g.action_dim);
+    CHK(launch_gemm(ah, st, &ctx->err));
+    ctx->dbg["hs"] = {ctx->hs, (int64_t)M * D};
+    return 0;
+}
+
+int engine_forward_infer(actmi_ctx* ctx, const float* qpos, const void* image, int fmt, int B, float* a_hat,
+                         hipStream_t st) {
+    ctx->err.clear();
+    if (!ctx->finalized) { ctx->err = "forward before finalize"; return ACTMI_E_STATE; }
+    if (B < 1 || B > ctx->cfg.max_batch) { ctx->err = "batch exceeds max_batch"; return ACTMI_E_INVALID; }
+    if (fmt != ACTMI_IMG_U8_NHWC && fmt != ACTMI_IMG_F32_NCHW) { ctx->err = "bad image format"; return ACTMI_E_INVALID; }
+    const actmi_config& g = ctx->cfg;
+    const int D = g.hidden_dim, N = ctx->N;
+    {
+        const int rc = engine_backbone(ctx, image, fmt, B, st);
+        if (rc == 1) return 0;
+        if (rc != 0) return rc;
+    }
+    // token 0: latent_input = latent_out_proj(0) = bias (detr_vae.py:158-159); token 1: proprio (detr_vae.py:213)
+    CHK(launch_fill_rows(ctx->X, D, (int64_t)N * D, ctx->P("latent_out_proj.bias"), 0, B, D, st));
+    CHK(launch_small_linear(qpos, g.state_dim, ctx->P("input_proj_robot_state.weight"),
+                            ctx->P("input_proj_robot_state.bias"), ctx->X + D, (int64_t)N * D, B, D, g.state_dim, st));
+    ctx->dbg["src"] = {ctx->X, (int64_t)B * N * D};
+    if (ctx->stop_stage == "src") return 0;
+    for (int l = 0; l < g.enc_layers; ++l)
+        CHK(engine_encoder_layer(ctx, ctx->enc[l], ctx->X, ctx->pos_tokens, B, N, nullptr, st));
+    ctx->dbg["memory"] = {ctx->X, (int64_t)B * N * D};
+    CHK(engine_decoder_infer(ctx, B, a_hat, st));
+    return 0;
+}

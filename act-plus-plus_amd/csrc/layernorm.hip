@@ -1,0 +1,97 @@
+// LayerNorm over the last dimension with fused residual add, one 64-lane wave per row, wave-shuffle
+// reductions (reference: nn.LayerNorm eps 1e-5 in transformer.py:200-201,261-263,35; the residual adds of
+// forward_post transformer.py:219-223, 284-294).  Optional second LayerNorm on top (decoder.norm applied to the
+// layer output, transformer.py:175).  Rows are held in registers (D <= 2048), two-pass mean / variance.
+#include "common.h"
+
+namespace {
+constexpr int MAXV = 8;   // float4 per lane -> D <= 64*4*8 = 2048
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                        int res_mod, const float* __restrict__ w,
+                                                        const float* __restrict__ b, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, float* __restrict__ y, int M,
+                                                        int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int D4 = D >> 2;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)row * D);
+    const f32x4* rr = res ? reinterpret_cast<const f32x4*>(res + (int64_t)(res_mod ? row % res_mod : row) * D) : nullptr;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D4) {
+            f32x4 t = xr[c];
+            if (rr) t += rr[c];
+            v[i] = t;
+            s += (t[0] + t[1]) + (t[2] + t[3]);
+        }
+    }
+    const float invD = 1.f / (float)D;
+    float mean = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (lane + 64 * i < D4) {
+            const f32x4 d = v[i] - mean;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    float rstd = 1.f / sqrtf(wave_sum(q) * invD + eps);
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D4) v[i] = (v[i] - mean) * rstd * w4[c] + b4[c];
+    }
+    if (w2) {
+        s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (lane + 64 * i < D4) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        mean = wave_sum(s) * invD;
+        q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            if (lane + 64 * i < D4) {
+                const f32x4 d = v[i] - mean;
+                q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
+        }
+        rstd = 1.f / sqrtf(wave_sum(q) * invD + eps);
+        const f32x4* w24 = reinterpret_cast<const f32x4*>(w2);
+        const f32x4* b24 = reinterpret_cast<const f32x4*>(b2);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D4) v[i] = (v[i] - mean) * rstd * w24[c] + b24[c];
+        }
+    }
+    f32x4* yr = reinterpret_cast<f32x4*>(y + (int64_t)row * D);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D4) yr[c] = v[i];
+    }
+}
+}  // namespace
+
+int launch_layernorm(const float* x, const float* res, int res_mod, const float* w, const float* b, const float* w2,
+                     const float* b2, float* y, int M, int D, float eps, hipStream_t st, std::string* err) {
+    if ((D & 3) || D > 64 * 4 * MAXV) { if (err) *err = "layernorm: D must be a multiple of 4 and <= 2048"; return -2; }
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, res, res_mod, w, b, w2, b2, y, M, D, eps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { if (err) *err = std::string("layernorm launch: ") + hipGetErrorString(e); return -3; }
+    return 0;
+}

@@ -1,0 +1,166 @@
+// Small kernels of the ACT path: tiny-K linears, token rows, weight repacking, temporal ensembling.
+#include "common.h"
+
+namespace {
+
+// y[m][n] = sum_k x[m][k] w[n][k] + b[n]  for the K in {14, 16, 32} projections
+// (input_proj_robot_state / encoder_joint_proj / encoder_action_proj / latent_out_proj; detr_vae.py:63,81-82,97)
+__global__ void small_linear_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                    const float* __restrict__ b, float* __restrict__ y, int64_t ldy, int M, int N,
+                                    int K) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    const int m = (int)(idx / N), n = (int)(idx - (int64_t)m * N);
+    const float* xr = x + (int64_t)m * ldx;
+    const float* wr = w + (int64_t)n * K;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(xr[k], wr[k], acc);
+    y[(int64_t)m * ldy + n] = acc + (b ? b[n] : 0.f);
+}
+
+__global__ void fill_rows_kernel(float* __restrict__ dst, int64_t batch_stride, const float* __restrict__ src,
+                                 int64_t src_bs, int B, int D) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * D) return;
+    const int b = (int)(idx / D), d = (int)(idx - (int64_t)b * D);
+    dst[(int64_t)b * batch_stride + d] = src[(int64_t)b * src_bs + d];
+}
+
+// [G][O][I][KH][KW] -> [G][O][kpad] with k = (r*KW + s)*I + c, zero padded
+__global__ void repack_conv_w_kernel(const float* __restrict__ in, float* __restrict__ out, int O, int I, int KH,
+                                     int KW, int64_t g_in, int64_t g_out, int kpad, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int k = (int)(idx % kpad);
+    int64_t rest = idx / kpad;
+    const int o = (int)(rest % O);
+    const int g = (int)(rest / O);
+    float v = 0.f;
+    if (k < KH * KW * I) {
+        const int c = k % I, rs = k / I, s = rs % KW, r = rs / KW;
+        v = in[g * g_in + (((int64_t)o * I + c) * KH + r) * KW + s];
+    }
+    out[g * g_out + (int64_t)o * kpad + k] = v;
+}
+
+// Temporal ensembling over E episodes (reference imitate_episodes.py:338-339, 402-411), one wave per episode.
+// ring[e][slot = t % Q][i][a] holds the chunk predicted at time t; at step t the rows r in [t-Q+1, t] contribute
+// chunk_r[t-r].  A row counts only when ALL its A values are != 0 ("actions_populated"); weights
+// exp(-k*i), i = 0 for the OLDEST populated row, normalised; products and sum in float64 as in the reference
+// (numpy float64 weights promote the float32 actions).
+__global__ __launch_bounds__(64) void ensemble_kernel(float* __restrict__ ring, int* __restrict__ tcount,
+                                                      const float* __restrict__ chunk, double k,
+                                                      double* __restrict__ out, uint8_t* __restrict__ populated,
+                                                      int Q, int A) {
+    extern __shared__ unsigned char s_pop[];   // Q flags, oldest first
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int t = tcount[e];
+    float* rg = ring + (int64_t)e * Q * Q * A;
+    const float* ch = chunk + (int64_t)e * Q * A;
+    float* slot = rg + (int64_t)(t % Q) * Q * A;
+    for (int i = lane; i < Q * A; i += 64) slot[i] = ch[i];
+    __syncthreads();
+    for (int j = lane; j < Q; j += 64) {
+        const int r = t - (Q - 1) + j;
+        bool pop = false;
+        if (r >= 0) {
+            const float* row = rg + ((int64_t)(r % Q) * Q + (t - r)) * A;
+            pop = true;
+            for (int a = 0; a < A; ++a) pop = pop && (row[a] != 0.f);
+        }
+        s_pop[j] = pop ? 1 : 0;
+        if (populated) populated[(int64_t)e * Q + j] = pop ? 1 : 0;
+    }
+    __syncthreads();
+    if (lane < A) {
+        int n = 0;
+        for (int j = 0; j < Q; ++j) n += s_pop[j];
+        double wsum = 0.0;
+        for (int i = 0; i < n; ++i) wsum += exp(-k * (double)i);
+        double acc = 0.0;
+        int i = 0;
+        for (int j = 0; j < Q; ++j) {
+            if (!s_pop[j]) continue;
+            const int r = t - (Q - 1) + j;
+            const double v = (double)rg[((int64_t)(r % Q) * Q + (t - r)) * A + lane];
+            acc += v * (exp(-k * (double)i) / wsum);
+            ++i;
+        }
+        out[(int64_t)e * A + lane] = acc;
+    }
+    __syncthreads();
+    if (lane == 0) tcount[e] = t + 1;
+}
+
+// FrozenBatchNorm2d folded to a per-channel affine, reference backbone.py:47-57:
+// scale = w * rsqrt(rv + 1e-5); bias = b - rm * scale   (IEEE sqrt and divide, as torch's CPU rsqrt)
+__global__ void bn_fold_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ rm,
+                               const float* __restrict__ rv, float* __restrict__ scale, float* __restrict__ bias, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = w[i] * (1.0f / sqrtf(rv[i] + 1e-5f));
+    scale[i] = s;
+    bias[i] = b[i] - rm[i] * s;
+}
+
+// feature row m = ((cam*B + b)*fh + h)*fw + w  ->  token row b*N + 2 + h*(fw*C) + cam*fw + w
+// (concat along width at detr_vae.py:216, flatten(2).permute at transformer.py:60, 2 extra tokens in front :102)
+__global__ void build_rowmap_kernel(int* __restrict__ map, int B, int C, int fh, int fw, int N) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= C * B * fh * fw) return;
+    const int w = m % fw;
+    int r = m / fw;
+    const int h = r % fh; r /= fh;
+    const int b = r % B;
+    const int cam = r / B;
+    map[m] = b * N + 2 + h * (fw * C) + cam * fw + w;
+}
+
+}  // namespace
+
+int launch_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale, float* bias, int n,
+                   hipStream_t st) {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, b, rm, rv, scale, bias, n);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_build_rowmap(int* map, int B, int C, int fh, int fw, int N, hipStream_t st) {
+    const int total = C * B * fh * fw;
+    hipLaunchKernelGGL(build_rowmap_kernel, dim3((total + 255) / 256), dim3(256), 0, st, map, B, C, fh, fw, N);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_small_linear(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int M,
+                        int N, int K, hipStream_t st) {
+    const int64_t total = (int64_t)M * N;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(small_linear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, ldx, w, b, y,
+                       ldy, M, N, K);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_fill_rows(float* dst, int64_t ld, int64_t batch_stride, const float* src, int64_t src_bs, int B, int D,
+                     hipStream_t st) {
+    (void)ld;
+    const int64_t total = (int64_t)B * D;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dst, batch_stride,
+                       src, src_bs, B, D);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_repack_conv_w(const float* w_oihw, float* w_ohwi, int G, int O, int I, int KH, int KW, int64_t g_in,
+                         int64_t g_out, int kpad, hipStream_t st) {
+    const int64_t total = (int64_t)G * O * kpad;
+    hipLaunchKernelGGL(repack_conv_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_oihw, w_ohwi,
+                       O, I, KH, KW, g_in, g_out, kpad, total);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_ensemble(float* ring, int* tcount, const float* chunk, double k, double* out, uint8_t* populated, int E,
+                    int Q, int A, hipStream_t st) {
+    if (E <= 0) return 0;
+    if (A > 64) return -2;
+    hipLaunchKernelGGL(ensemble_kernel, dim3(E), dim3(64), Q, st, ring, tcount, chunk, k, out, populated, Q, A);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -1,0 +1,42 @@
+// 3x3 / stride 2 / pad 1 max pooling on NHWC maps (torchvision resnet ``maxpool``).  HBM-bound:
+// each thread produces 4 channels (one float4) of one output pixel; consecutive lanes walk the channel
+// dimension first so that every load/store instruction covers whole 16-byte-per-lane contiguous runs.
+#include "common.h"
+
+namespace {
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                      int H, int W, int C4, int Ho, int Wo, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        int64_t pix = idx / C4;
+        const int wo = (int)(pix % Wo); pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int64_t img = pix / Ho;
+        const f32x4* src = reinterpret_cast<const f32x4*>(in) + img * H * W * C4 + c4;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = 2 * ho - 1 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int wi = 2 * wo - 1 + s;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const f32x4 v = src[((int64_t)hi * W + wi) * C4];
+                m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+            }
+        }
+        reinterpret_cast<f32x4*>(out)[idx] = m;
+    }
+}
+}  // namespace
+
+int launch_maxpool(const float* in, float* out, int nimg, int H, int W, int C, int Ho, int Wo, hipStream_t st) {
+    if (C & 3) return -2;
+    const int64_t total = (int64_t)nimg * Ho * Wo * (C / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, H, W, C / 4, Ho, Wo, total);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

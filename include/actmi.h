@@ -1,0 +1,157 @@
+/*
+ * libactmi -- C ABI of the MI355X-native ACT policy path (gfx950).
+ *
+ * This header is the drop-in boundary below the reference's Python policy adaptor.  The reference owns no
+ * native code: its ACT arithmetic is reached through `ACTPolicy.__call__(qpos, image, actions, is_pad)`
+ * (reference policy.py:264-332) which calls `DETRVAE.forward` (detr/models/detr_vae.py:163-254); the
+ * optimizer is `torch.optim.AdamW` built at detr/main.py:102-110 and the temporal ensemble is inline
+ * in `eval_bc` (imitate_episodes.py:402-411).  Each entry point below names the reference interface it
+ * replaces.  Plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers valid on
+ * the handle's device unless a parameter is documented as host memory; `stream` is a hipStream_t passed
+ * as void*.  Every function returns 0 on success or a negative ACTMI_E_* code and never throws;
+ * `actmi_last_error` returns the message.  A handle is bound to one device and is not re-entrant.
+ */
+#ifndef ACTMI_H
+#define ACTMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACTMI_VERSION 100
+
+#define ACTMI_OK 0
+#define ACTMI_E_INVALID (-1)   /* bad argument / unknown key / shape mismatch */
+#define ACTMI_E_SHAPE (-2)     /* operand shape or alignment not supported by a kernel */
+#define ACTMI_E_LAUNCH (-3)    /* HIP launch or runtime error */
+#define ACTMI_E_STATE (-4)     /* call order (e.g. forward before finalize, backward before forward_train) */
+#define ACTMI_E_NOMEM (-5)
+
+#define ACTMI_IMG_U8_NHWC 0    /* [B][C][H][W][3] uint8, the on-disk / simulator format (utils.py:104) */
+#define ACTMI_IMG_F32_NCHW 1   /* [B][C][3][H][W] float32 in [0,1], the ACTPolicy.__call__ contract */
+
+typedef struct actmi_ctx* actmi_handle;
+
+/* Model hyper-parameters: reference imitate_episodes.py:78-94 + detr/main.py:12-89 defaults. */
+typedef struct actmi_config {
+    int32_t num_cams;
+    int32_t image_h, image_w;
+    int32_t base_width;        /* resnet18 stem width (64) */
+    int32_t hidden_dim, nheads, dim_feedforward;
+    int32_t enc_layers, dec_layers;
+    int32_t num_queries, state_dim, action_dim, latent_dim;
+    int32_t has_cvae_encoder;  /* 0 when --no_encoder */
+    int32_t max_batch;         /* workspace is sized for this batch at create time */
+    int32_t enable_training;   /* allocate gradient / optimizer / saved-activation storage */
+    float kl_weight;
+} actmi_config;
+
+/* GEMM / implicit-GEMM convolution descriptor (also the unit-test entry of the MFMA kernel):
+ * C[rowmap(m)][n] = act((sum_k A'[m][k] * Bw[n][k]) * scale[n] + bias[n] + res[m % res_mod][n]).
+ * Replaces ATen addmm / cuDNN convolution as launched by nn.Linear, nn.MultiheadAttention projections and
+ * torchvision Conv2d+FrozenBatchNorm2d (backbone.py:47-57). */
+typedef struct actmi_gemm_desc {
+    const float* A;
+    int64_t lda;
+    int32_t mode;              /* 0 = row-major A, 1 = NHWC implicit im2col, K index = (r*KW+s)*Cin+c */
+    int32_t H, W, Cin, KH, KW, stride, pad, Ho, Wo;
+    int64_t img_stride;
+    const float* A_add;        /* optional: A'[m][k] = A[m][k] + A_add[m % add_mod][k] for columns n < add_ncols */
+    int64_t ld_add;
+    int32_t add_mod;
+    int32_t add_ncols;
+    const float* Bw;           /* [N][K] row-major (torch Linear layout) */
+    int64_t ldb;
+    const float* scale;        /* per-n or NULL */
+    const float* bias;         /* per-n or NULL */
+    const float* res;          /* residual or NULL */
+    int64_t ldres;
+    int32_t res_mod;
+    int32_t relu;
+    float* C;
+    int64_t ldc;
+    const int32_t* rowmap;
+    int32_t M, N, K;
+    int32_t groups;            /* blockIdx.z; per-group element offsets below */
+    int64_t gA, gB, gSB, gC, gRes;
+} actmi_gemm_desc;
+
+/* Multi-head attention descriptor: softmax(scale * q k^T [+ key padding mask]) v per (batch, head).
+ * Replaces nn.MultiheadAttention's bmm/softmax/bmm (transformer.py:217-218, 282-289). */
+typedef struct actmi_attn_desc {
+    const float* Q; int64_t q_bs, q_rs;
+    const float* K; int64_t k_bs, k_rs;
+    const float* V; int64_t v_bs, v_rs;
+    float* O; int64_t o_bs, o_rs;
+    const uint8_t* kpm; int64_t kpm_bs;
+    float* lse;
+    int32_t B, H, Nq, Nk, HD;
+    float scale;
+} actmi_attn_desc;
+
+int actmi_version(void);
+
+/* ---- lifecycle ------------------------------------------------------------------------------------ */
+/* replaces build_ACT_model_and_optimizer (detr/main.py:92-112) without touching sys.argv */
+int actmi_create(const actmi_config* cfg, actmi_handle* out);
+int actmi_destroy(actmi_handle h);
+const char* actmi_last_error(actmi_handle h);   /* h may be NULL: last error of a failed create */
+
+/* state_dict wire format (policy.py:344-348 serialize/deserialize): keys WITHOUT the "model." prefix,
+ * float32, shapes as in the reference state_dict.  src/dst are host pointers unless is_device != 0. */
+int actmi_num_params(actmi_handle h);
+int actmi_param_info(actmi_handle h, int index, const char** key, int64_t* shape4, int* ndim, int* is_buffer);
+int actmi_set_param(actmi_handle h, const char* key, const void* src, const int64_t* shape, int ndim, int is_device);
+int actmi_get_param(actmi_handle h, const char* key, void* dst, int64_t nbytes, int is_device);
+/* fold FrozenBN, repack conv weights, build position tables and the constant decoder query path.
+ * Must be called after the last set_param and before the first forward. */
+int actmi_finalize(actmi_handle h, void* stream);
+
+/* ---- inference: ACTPolicy.__call__(qpos, image) -> a_hat (policy.py:322-332) ----------------------- */
+int actmi_forward_infer(actmi_handle h, const float* qpos /*[B][S]*/, const void* image, int image_fmt, int B,
+                        float* a_hat /*[B][Q][A]*/, void* stream);
+
+/* ---- training: ACTPolicy.__call__(qpos, image, actions, is_pad) -> {l1, kl, loss} (policy.py:288-320) -- */
+int actmi_forward_train(actmi_handle h, const float* qpos, const void* image, int image_fmt,
+                        const float* actions /*[B][Q][A]*/, const uint8_t* is_pad /*[B][Q]*/,
+                        const float* eps /*[B][L]*/, uint64_t dropout_seed, float dropout_p, int B,
+                        float* losses /*[3] l1, kl, loss*/, float* a_hat, float* mu, float* logvar, void* stream);
+/* loss.backward() (imitate_episodes.py:606) */
+int actmi_backward(actmi_handle h, float loss_scale, void* stream);
+/* optimizer.zero_grad() / optimizer.step() with the two AdamW groups of detr/main.py:102-110 */
+int actmi_zero_grad(actmi_handle h, void* stream);
+int actmi_adamw_step(actmi_handle h, float lr, float lr_backbone, float weight_decay, float beta1, float beta2,
+                     float eps, int64_t step, void* stream);
+int actmi_grad_ptr(actmi_handle h, const char* key, void** dev_ptr, int64_t* numel);
+
+/* ---- temporal ensembling over E episodes (imitate_episodes.py:338-339, 402-411) ------------------- */
+/* ring [E][Q][Q][A] f32 zero-initialised, tcount [E] i32 zero-initialised, chunk [E][Q][A] f32;
+ * out [E][A] f64 (the reference's raw_action is float64), populated [E][Q] u8 or NULL (oldest row first). */
+int actmi_ensemble_step(float* ring, int32_t* tcount, const float* chunk, double k, double* out, uint8_t* populated,
+                        int E, int Q, int A, void* stream);
+
+/* ---- kernel-level entry points (unit tests, external callers) --------------------------------------- */
+int actmi_op_gemm(const actmi_gemm_desc* d, void* stream);
+int actmi_op_attention(const actmi_attn_desc* d, void* stream);
+int actmi_op_layernorm(const float* x, const float* res, int res_mod, const float* w, const float* b, const float* w2,
+                       const float* b2, float* y, int M, int D, float eps, void* stream);
+int actmi_op_maxpool3x3s2(const float* in_nhwc, float* out_nhwc, int nimg, int H, int W, int C, void* stream);
+/* conv1: w is the torch OIHW [C][Cout][3][7][7] weight, scale/bias the folded FrozenBN; out camera-major NHWC */
+int actmi_op_conv1(const void* image, int image_fmt, const float* w_oihw, const float* scale, const float* bias,
+                   float* out, float* workspace /* >= C*Cout*148 + 768 floats */, int B, int C, int H, int W, int Cout,
+                   void* stream);
+const char* actmi_op_last_error(void);
+
+/* intermediate activations of the last forward (parity tests): name in {"conv1","maxpool","layer1".."layer4",
+ * "src","memory","hs"}; camera-major NHWC for the maps, [B][N][D] for tokens. */
+int actmi_debug_tensor(actmi_handle h, const char* name, const float** dev_ptr, int64_t* numel);
+/* debug: make the next forwards return right after the named stage ("" = run everything); the maps of the
+ * trunk live in rotating buffers, so a stage is only readable when the forward stopped there. */
+int actmi_debug_stop_after(actmi_handle h, const char* stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACTMI_H */

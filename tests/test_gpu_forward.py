@@ -1,0 +1,133 @@
+"""End-to-end parity of the HIP inference path: golden fixtures produced by the reference's own modules
+(tests/golden, tools/gen_golden.py) and the CPU oracle on other batch sizes.
+Bar (BASELINE.json north_star): |a_hat - reference| <= 1e-4 absolute, fp32."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import load_fixture, regenerate, sample_like, torch_sd  # noqa: E402
+from actmi import weights as W  # noqa: E402
+from actmi.engine import ACTEngine  # noqa: E402
+
+ATOL = 1e-4
+
+
+def _engine(cfg, sd_np, max_batch):
+    eng = ACTEngine(cfg, max_batch=max_batch)
+    eng.load_state_dict(sd_np)
+    eng.finalize()
+    return eng
+
+
+def _to_nchw(t, G, B):
+    """camera-major NHWC [G*B,H,W,C] flat -> [B,C,H,W] of camera 0 for comparison with the oracle's NCHW maps."""
+    return t
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_c3", "full3", "full4"])
+def test_forward_matches_reference_golden(name):
+    z, cfg = load_fixture(name)
+    sd_np, inp = regenerate(z, cfg, with_actions=True)
+    B = int(z["batch"])
+    eng = _engine(cfg, sd_np, B)
+    d = eng.device
+    qpos = torch.from_numpy(inp["qpos"]).to(d)
+    img_u8 = torch.from_numpy(inp["image_u8"]).to(d)
+    a = eng.forward_infer(qpos, img_u8).cpu().numpy()
+    err = np.abs(a - z["infer.a_hat"]).max()
+    print(f"{name}: max|a_hat - ref| = {err:.3e}")
+    assert err <= ATOL
+    # the reference's own input contract (f32 NCHW in [0,1]) gives the same result
+    img_f32 = torch.from_numpy(W.u8_nhwc_to_f32_nchw(inp["image_u8"])).to(d)
+    a2 = eng.forward_infer(qpos, img_f32).cpu().numpy()
+    assert np.abs(a2 - z["infer.a_hat"]).max() <= ATOL
+    # hs of decoder layer 0
+    hs = eng.debug_tensor("hs").cpu().numpy()
+    assert np.abs(sample_like(hs, z) - z["infer.hs"].reshape(-1)).max() <= 2e-4
+    # stage activations (camera 0 is the first B images of the camera-major maps)
+    fh, fw = cfg.feat_hw
+    for stage in ["conv1", "maxpool", "layer1", "layer4", "src"]:
+        eng.debug_stop_after(stage)
+        eng.forward_infer(qpos, img_u8)
+        t = eng.debug_tensor(stage).cpu()
+        key = "stage." + (stage if stage == "src" else "cam0_" + stage)
+        exp = z[key].reshape(-1)
+        if stage == "src":
+            got = t.view(B, cfg.num_tokens, cfg.hidden_dim).permute(1, 0, 2)         # reference is [N,B,D]
+        else:
+            Cc = t.numel() // (cfg.num_cams * B)
+            full = t.view(cfg.num_cams, B, -1)
+            got0 = full[0]
+            # recover H,W,C of the map
+            ref_shape = {"conv1": (cfg.image_h // 2, cfg.image_w // 2, cfg.base_width)}
+            ch = {"conv1": cfg.base_width, "maxpool": cfg.base_width, "layer1": cfg.base_width,
+                  "layer4": 8 * cfg.base_width}[stage]
+            hw = got0.shape[1] // ch
+            # H/W from the conv arithmetic
+            def down(x, k, s, p):
+                return (x + 2 * p - k) // s + 1
+            h, w = down(cfg.image_h, 7, 2, 3), down(cfg.image_w, 7, 2, 3)
+            if stage != "conv1":
+                h, w = down(h, 3, 2, 1), down(w, 3, 2, 1)
+            if stage == "layer4":
+                h, w = fh, fw
+            assert h * w == hw
+            got = got0.view(B, h, w, ch).permute(0, 3, 1, 2)                           # NCHW like the reference hook
+        g = sample_like(got.contiguous().numpy(), z)
+        tol = 1e-4 * max(1.0, float(np.abs(exp).max()))
+        assert np.abs(g - exp).max() <= tol, stage
+    eng.debug_stop_after("")
+
+
+def test_forward_batch_sizes_against_oracle():
+    """Other batch sizes than the fixtures', checked against the CPU oracle (same seeded inputs)."""
+    from oracle import act_ref as R
+    from actmi.config import tiny_config
+    cfg = tiny_config(camera_names=["a", "b", "c"], image_h=96, image_w=128)
+    sd_np = W.generate_state_dict(cfg, seed=11)
+    eng = _engine(cfg, sd_np, 5)
+    sd = torch_sd(sd_np)
+    for B in (1, 5, 3):
+        inp = W.generate_inputs(cfg, B, seed=100 + B)
+        with torch.no_grad():
+            exp = R.policy_call(sd, cfg, torch.from_numpy(inp["qpos"]),
+                                torch.from_numpy(W.u8_nhwc_to_f32_nchw(inp["image_u8"]))).numpy()
+        got = eng.forward_infer(torch.from_numpy(inp["qpos"]).cuda(), torch.from_numpy(inp["image_u8"]).cuda()).cpu().numpy()
+        assert np.abs(got - exp).max() <= ATOL
+
+
+def test_batch_independence_and_determinism():
+    """Size-independent properties at the benchmark configuration (C=4, 480x640, B=8): a sample's output does not
+    depend on its batch neighbours (FrozenBN => no batch statistics) and repeated runs are bit-identical."""
+    from actmi.config import ACTConfig
+    cfg = ACTConfig()
+    sd_np = W.generate_state_dict(cfg, seed=0)
+    eng = _engine(cfg, sd_np, 8)
+    inp = W.generate_inputs(cfg, 8, seed=5)
+    q = torch.from_numpy(inp["qpos"]).cuda()
+    im = torch.from_numpy(inp["image_u8"]).cuda()
+    a8 = eng.forward_infer(q, im).clone()
+    a8b = eng.forward_infer(q, im).clone()
+    assert torch.equal(a8, a8b)
+    a1 = eng.forward_infer(q[3:4].contiguous(), im[3:4].contiguous())
+    assert float((a1[0] - a8[3]).abs().max()) <= 2e-5
+    assert torch.isfinite(a8).all()
+
+
+def test_state_dict_round_trip_and_errors():
+    from actmi.config import tiny_config
+    cfg = tiny_config()
+    sd_np = W.generate_state_dict(cfg, seed=2)
+    eng = ACTEngine(cfg, max_batch=2)
+    eng.load_state_dict({"model." + k: v for k, v in sd_np.items()}, prefix="model.")
+    back = eng.state_dict(prefix="model.")
+    assert list(back.keys()) == ["model." + k for k in sd_np]
+    for k, v in sd_np.items():
+        assert np.array_equal(back["model." + k].numpy(), v)
+    with pytest.raises(RuntimeError):
+        eng.load_state_dict({"bogus": np.zeros(3, np.float32)})
+    with pytest.raises(ValueError):
+        eng.forward_infer(torch.zeros(3, cfg.state_dim).cuda(),
+                          torch.zeros(3, cfg.num_cams, cfg.image_h, cfg.image_w, 3, dtype=torch.uint8).cuda())
