@@ -90,6 +90,9 @@ def load():
         "actmi_op_last_error": ([], C.c_char_p),
         "actmi_debug_tensor": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i64)], i32),
         "actmi_debug_stop_after": ([vp, C.c_char_p], i32),
+        "actmi_profile_enable": ([i32], i32),
+        "actmi_profile_reset": ([], i32),
+        "actmi_profile_report": ([C.c_char_p, i32], i32),
     }
     for name, (args, res) in sigs.items():
         fn = getattr(lib, name)          # AttributeError here = header and library disagree
@@ -115,3 +118,20 @@ def check(rc, handle=None, what=""):
         lib = load()
         msg = lib.actmi_last_error(handle) if handle is not None else lib.actmi_op_last_error()
         raise RuntimeError(f"libactmi {what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def profile_enable(on: bool):
+    lib = load()
+    lib.actmi_profile_reset() if on else None
+    lib.actmi_profile_enable(1 if on else 0)
+
+
+def profile_report():
+    """-> list of {name,count,ms,flops,bytes}; synchronises the recorded events."""
+    import json
+    lib = load()
+    buf = C.create_string_buffer(1 << 16)
+    rc = lib.actmi_profile_report(buf, len(buf))
+    if rc != 0:
+        raise RuntimeError(f"actmi_profile_report failed ({rc})")
+    return json.loads(buf.value.decode())

@@ -12,6 +12,7 @@
 // movement).  The head-dim contraction order is free, so lane-half h takes d = h*HD/2 + s at step s and reads
 // K rows as ds_read_b128 (row stride HD+4 floats: conflict-free); V is read as ds_read_b32 along d.
 #include "common.h"
+#include <cstdio>
 
 namespace {
 
@@ -155,12 +156,19 @@ int launch_attention(const AttnArgs& a, hipStream_t st, std::string* err) {
     if (((uintptr_t)a.Q & 15) || ((uintptr_t)a.K & 15) || ((uintptr_t)a.V & 15) || ((uintptr_t)a.O & 15))
         return fail("pointers must be 16-byte aligned");
     dim3 grid((a.Nq + 127) / 128, a.H, a.B);
+    if (prof_enabled()) {
+        char nm[48];
+        snprintf(nm, sizeof(nm), "attn_f32_kernel<%d>", a.HD);
+        prof_begin(nm, 4.0 * a.B * a.H * (double)a.Nq * a.Nk * a.HD,
+                   4.0 * a.B * a.H * a.HD * (2.0 * a.Nq + 2.0 * a.Nk), st);
+    }
     switch (a.HD) {
         case 64: hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(256), 0, st, a); break;
         case 32: hipLaunchKernelGGL(attn_f32_kernel<32>, grid, dim3(256), 0, st, a); break;
         case 16: hipLaunchKernelGGL(attn_f32_kernel<16>, grid, dim3(256), 0, st, a); break;
         default: return fail("head_dim must be 16, 32 or 64");
     }
+    prof_end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (err) *err = std::string("attention launch: ") + hipGetErrorString(e); return -3; }
     return 0;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <cstring>
 #include "actmi.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -58,3 +59,8 @@ int launch_ensemble(float* ring, int* tcount, const float* chunk, double k, doub
 int launch_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale, float* bias, int n,
                    hipStream_t st);
 int launch_build_rowmap(int* map, int B, int C, int fh, int fw, int N, hipStream_t st);
+
+// ---- per-launch event profiler (prof.hip) ------------------------------------------------------------
+bool prof_enabled();
+void prof_begin(const char* name, double flops, double bytes, hipStream_t st);
+void prof_end(hipStream_t st);

@@ -121,8 +121,11 @@ int launch_conv1(const Conv1Args& a, hipStream_t st, std::string* err) {
     const int per = (tiles_per_cam + gx - 1) / gx;
     gx = (tiles_per_cam + per - 1) / per;
     dim3 grid(gx, a.C);
+    prof_begin(a.fmt == 0 ? "conv1_kernel<0>" : "conv1_kernel<1>", 2.0 * a.B * a.C * a.Ho * a.Wo * a.Cout * 147.0,
+               (double)a.B * a.C * ((double)a.H * a.W * 3 * (a.fmt == 0 ? 1 : 4) + 4.0 * a.Ho * a.Wo * a.Cout), st);
     if (a.fmt == 0) hipLaunchKernelGGL(conv1_kernel<0>, grid, dim3(256), 0, st, a, tiles_per_row, tiles_per_cam);
     else hipLaunchKernelGGL(conv1_kernel<1>, grid, dim3(256), 0, st, a, tiles_per_row, tiles_per_cam);
+    prof_end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (err) *err = std::string("conv1 launch: ") + hipGetErrorString(e); return -3; }
     return 0;

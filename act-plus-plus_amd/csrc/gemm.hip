@@ -15,6 +15,7 @@
 // Planes are padded by one float4 so that the 8 lanes that write one row's 8 chunks hit 8 different
 // 16-byte bank groups (ds_write_b128 is serviced 8 lanes at a time).
 #include "common.h"
+#include <cstdio>
 
 namespace {
 
@@ -220,7 +221,16 @@ int launch_cfg(const GemmArgs& a, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid(tiles_m * tiles_n, 1, a.groups > 0 ? a.groups : 1);
+    if (prof_enabled()) {
+        char nm[64];
+        snprintf(nm, sizeof(nm), "gemm_f32_kernel<%d,%d,%d,%d,%d>", BM, BN, WM, WN, MODE);
+        const double g = a.groups;
+        // algorithmic work: 2*M*N*K flops; operands read once + result written once
+        prof_begin(nm, 2.0 * a.M * a.N * a.K * g, 4.0 * g * ((double)a.M * a.N + (double)a.N * a.K +
+                   (MODE == 0 ? (double)a.M * a.K : (double)(a.M / (a.Ho * a.Wo)) * a.H * a.W * a.Cin)), st);
+    }
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a, tiles_m, tiles_n);
+    prof_end(st);
     return (int)hipGetLastError();
 }
 

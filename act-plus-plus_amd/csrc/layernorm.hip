@@ -90,7 +90,9 @@ int launch_layernorm(const float* x, const float* res, int res_mod, const float*
                      const float* b2, float* y, int M, int D, float eps, hipStream_t st, std::string* err) {
     if ((D & 3) || D > 64 * 4 * MAXV) { if (err) *err = "layernorm: D must be a multiple of 4 and <= 2048"; return -2; }
     if (M <= 0) return 0;
+    prof_begin("layernorm_kernel", 0.0, 4.0 * M * D * (res && !res_mod ? 3.0 : 2.0), st);
     hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, res, res_mod, w, b, w2, b2, y, M, D, eps);
+    prof_end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (err) *err = std::string("layernorm launch: ") + hipGetErrorString(e); return -3; }
     return 0;

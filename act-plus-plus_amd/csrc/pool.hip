@@ -37,6 +37,8 @@ int launch_maxpool(const float* in, float* out, int nimg, int H, int W, int C, i
     const int64_t total = (int64_t)nimg * Ho * Wo * (C / 4);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
+    prof_begin("maxpool_kernel", 0.0, 4.0 * nimg * C * ((double)H * W + (double)Ho * Wo), st);
     hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, H, W, C / 4, Ho, Wo, total);
+    prof_end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ACT policy steps/sec on synthetic 4-camera 480x640 batches (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one batched policy query through the C-ABI HIP path: u8 NHWC images already resident in HBM ->
+multi-camera ResNet18 -> DETR encoder/decoder -> a_hat [B,100,16] -> temporal-ensemble reduction.  Weights are
+random-init of the reference architecture (no network for checkpoints), inputs synthetic; work per step is
+independent of the values.  N > 1 runs N independent replicas on disjoint batches (episodes shard embarrassingly;
+the path has no data-path collective) and reports the whole-job aggregate with max-over-ranks timing.
+
+Rank 0 prints ONE JSON line with the driver's contract plus:
+  roofline     dominant kernel (the fp32 MFMA GEMM/implicit-conv instantiation with the largest total time):
+               achieved = algorithmic FLOPs of its launches / their summed duration, measured with HIP events
+               on the launch stream inside the timed region; peak = 157.3 TFLOP/s (fp32 matrix, MI355X_MICROARCH.md)
+  cpu_baseline the CPU oracle (torch fp32 restatement of the reference, as written: all 7 decoder layers) timed on
+               this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "act-plus-plus_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3          # MI355X_MICROARCH.md, chip-level parameters
+GFLOP_PER_SAMPLE_LIVE = 145.4            # work that influences the output (decoder layer 0 only)
+GFLOP_PER_SAMPLE_AS_WRITTEN = 160.4
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (metric is quoted at 8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from actmi.config import ACTConfig
+    from actmi import weights as W
+    from actmi import lib as L
+    from actmi import ops
+    from actmi.engine import ACTEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})",
+              file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
+
+    cfg = ACTConfig()                                           # C=4, 480x640, Q=100, D=512, F=3200, 4 enc + 7 dec
+    B = args.batch
+    log(f"rank {rank}/{world}: generating weights")
+    eng = ACTEngine(cfg, max_batch=B, device=str(dev))
+    eng.load_state_dict(W.generate_state_dict(cfg, seed=0))
+    eng.finalize()
+    log("engine ready")
+    inp = W.generate_inputs(cfg, B, seed=1234 + rank)
+    qpos = torch.from_numpy(inp["qpos"]).to(dev)
+    image = torch.from_numpy(inp["image_u8"]).to(dev)           # resident in HBM before the timed region
+    a_hat = torch.empty((B, cfg.num_queries, cfg.action_dim), dtype=torch.float32, device=dev)
+    ens = ops.TemporalEnsemble(B, cfg.num_queries, cfg.action_dim, 0.01, dev)
+
+    def step():
+        eng.forward_infer(qpos, image, out=a_hat)
+        return ens.step(a_hat)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    log("warm-up done")
+    L.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    t1 = time.perf_counter()
+    L.profile_enable(False)
+    prof = L.profile_report()
+    log(f"timed region done: {(t1 - t0) / args.steps * 1e3:.2f} ms/step")
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(a_hat).all()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        # dominant kernel
+        prof = [p for p in prof if p["ms"] > 0]
+        prof.sort(key=lambda p: -p["ms"])
+        dom = prof[0]
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        gpu_ms = sum(p["ms"] for p in prof)
+        kernels = [{"name": p["name"], "launches_per_step": p["count"] / args.steps,
+                    "avg_us": p["ms"] * 1e3 / p["count"], "share": p["ms"] / gpu_ms,
+                    "tflops": (p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["flops"] else None,
+                    "gbps": p["bytes"] / (p["ms"] * 1e-3) / 1e9} for p in prof]
+        out = {
+            "metric": "policy steps/sec (4x480x640 cams, chunk=100, bs=8)",
+            "value": value, "unit": "policy steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ACT eval policy query: 4 cams 480x640 u8, chunk 100, hidden 512, ff 3200, "
+                                   "4 enc + 7 dec layers (layer 0 live), per-GPU batch %d, + temporal ensemble" % B,
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"replicas x{world}"},
+            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "avg_launch_us": dom["ms"] * 1e3 / dom["count"], "launches_per_step": dom["count"] / args.steps,
+                         "flop_per_launch": dom["flops"] / dom["count"]},
+            "whole_step": {"gflop_per_sample_live": GFLOP_PER_SAMPLE_LIVE,
+                           "achieved_tflops_live": value / world * GFLOP_PER_SAMPLE_LIVE / 1e3,
+                           "frac_of_fp32_matrix_peak": value / world * GFLOP_PER_SAMPLE_LIVE / 1e3 / PEAK_FP32_MATRIX_TFLOPS,
+                           "gpu_kernel_ms_per_step": gpu_ms / args.steps},
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, B, args.cpu_iters)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, B, iters):
+    """Time the oracle (CPU restatement of the reference forward, fp32, as written) on the host cores."""
+    import torch
+    from actmi import weights as W
+    from oracle import act_ref as R
+    # the GPU box gives a 1-GPU job a 16-core CPU share; more threads than that only thrash
+    ncores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), int(os.environ.get("ACTMI_CPU_THREADS", "16")))
+    torch.set_num_threads(ncores)
+    log(f"cpu baseline: {ncores} threads")
+    sd = {"model." + k: torch.from_numpy(v) for k, v in W.generate_state_dict(cfg, seed=0).items()}
+    inp = W.generate_inputs(cfg, B, seed=1234)
+    qpos = torch.from_numpy(inp["qpos"])
+    image = torch.from_numpy(W.u8_nhwc_to_f32_nchw(inp["image_u8"]))
+    with torch.no_grad():
+        R.policy_call(sd, cfg, qpos[:1], image[:1])               # warm-up
+        log("cpu baseline: warm-up done")
+        t0 = time.perf_counter()
+        done = 0
+        for _ in range(iters):
+            R.policy_call(sd, cfg, qpos, image)
+            done += 1
+            log(f"cpu baseline: {done} forwards in {time.perf_counter() - t0:.1f} s")
+            if time.perf_counter() - t0 > 30.0:
+                break
+        dt = time.perf_counter() - t0
+        iters = done
+    return {"value": B * iters / dt, "unit": "policy steps/s", "cores": ncores, "kind": "port",
+            "sample": f"{iters} forwards of batch {B} (same workload, as-written 7 decoder layers) after 1 warm-up; "
+                      f"torch {torch.__version__} CPU fp32, {ncores} threads"}
+
+
+if __name__ == "__main__":
+    main()

@@ -151,6 +151,13 @@ int actmi_debug_tensor(actmi_handle h, const char* name, const float** dev_ptr, 
  * trunk live in rotating buffers, so a stage is only readable when the forward stopped there. */
 int actmi_debug_stop_after(actmi_handle h, const char* stage);
 
+/* ---- per-launch HIP-event profiler (bench.py roofline leg) --------------------------------------- */
+/* When enabled, every kernel launch of the library is bracketed by two events on its stream.  The report is a
+ * JSON array of {"name","count","ms","flops","bytes"} per kernel instantiation (algorithmic flops/bytes). */
+int actmi_profile_enable(int on);
+int actmi_profile_reset(void);
+int actmi_profile_report(char* buf, int buflen);
+
 #ifdef __cplusplus
 }
 #endif
