@@ -1,0 +1,38 @@
+"""One process per GPU over torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" for CPU tests)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env():
+    """Initialise from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* if a launcher set them. Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local_rank
+
+
+def all_gather_rows(local: torch.Tensor, counts):
+    """Gather variable-length [n_r, k] float tensors from every rank into one [sum n_r, k] CPU tensor
+    (the single collective of the eval path: per-episode (return, highest_reward))."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local.detach().cpu()
+    world = dist.get_world_size()
+    nmax = max(counts)
+    k = local.shape[1]
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    pad = torch.zeros((nmax, k), dtype=torch.float32, device=dev)
+    pad[: local.shape[0]] = local.to(dev, torch.float32)
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad)
+    return torch.cat([o[:c].cpu() for o, c in zip(outs, counts)], dim=0)

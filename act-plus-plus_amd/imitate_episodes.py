@@ -1,0 +1,355 @@
+"""Train / eval entry points of the ACT path with the reference's names and CLI
+(reference imitate_episodes.py: main :37, make_policy :182, make_optimizer :194, get_image :206, eval_bc :228,
+forward_pass :529, train_bc :535, repeater :624, CLI :633-666), re-designed for MI355X:
+
+* eval rollouts are BATCHED: E episodes step in lock-step, one policy query of batch E per timestep through
+  libactmi, one temporal-ensemble kernel for all episodes, envs stepped by host threads (the reference runs
+  episodes one after another with batch 1, :319-353);
+* episodes SHARD across ranks (one process per GPU): poses are pre-drawn in the reference's RNG order, every rank
+  takes a contiguous slice, a single all-gather of (episode_return, highest_reward) ends the run;
+* the 10 warm-up queries per rollout and the real-time sleep (:377-382, :467-470) are off by default.
+"""
+import argparse
+import os
+import pickle
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+from copy import deepcopy
+from itertools import repeat
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+
+from actmi.constants import FPS, SIM_TASK_CONFIGS  # noqa: E402
+from actmi.sim_utils import compute_dict_mean, draw_episode_poses, set_seed, shard_range  # noqa: E402
+from actmi import dist_utils  # noqa: E402
+
+
+def make_policy(policy_class, policy_config):
+    """reference imitate_episodes.py:182-191 (ACT only on this path)."""
+    if policy_class == "ACT":
+        from policy import ACTPolicy
+        return ACTPolicy(policy_config)
+    raise NotImplementedError(f"policy_class {policy_class} is outside the accelerated path (SURVEY §2)")
+
+
+def make_optimizer(policy_class, policy):
+    """reference imitate_episodes.py:194-203."""
+    if policy_class == "ACT":
+        return policy.configure_optimizers()
+    raise NotImplementedError
+
+
+def get_image(ts, camera_names, rand_crop_resize=False):
+    """reference imitate_episodes.py:206-225: one timestep -> f32 [1,C,3,H,W] in [0,1] on the GPU."""
+    if rand_crop_resize:
+        raise NotImplementedError("rand_crop_resize is only used by the Diffusion policy")
+    imgs = np.stack([np.moveaxis(ts.observation["images"][c], -1, 0) for c in camera_names], axis=0)
+    return torch.from_numpy(imgs / 255.0).float().cuda().unsqueeze(0)
+
+
+def get_image_batch_u8(ts_list, camera_names, pinned=None):
+    """Fast path of the same contract: E timesteps -> u8 [E,C,H,W,3] (4x fewer H2D bytes; /255 and the ImageNet
+    normalisation are fused into the conv1 loader with the reference's float arithmetic)."""
+    E, C = len(ts_list), len(camera_names)
+    h, w, _ = ts_list[0].observation["images"][camera_names[0]].shape
+    if pinned is None or tuple(pinned.shape) != (E, C, h, w, 3):
+        pinned = torch.empty((E, C, h, w, 3), dtype=torch.uint8)
+        if torch.cuda.is_available():
+            pinned = pinned.pin_memory()
+    buf = pinned.numpy()
+    for e, ts in enumerate(ts_list):
+        for c, name in enumerate(camera_names):
+            buf[e, c] = ts.observation["images"][name]
+    return pinned
+
+
+def _default_stats(state_dim, action_dim=16):
+    return {"qpos_mean": np.zeros(state_dim), "qpos_std": np.ones(state_dim),
+            "action_mean": np.zeros(action_dim), "action_std": np.ones(action_dim)}
+
+
+def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, ensemble_factory=None,
+            env_factory=None, stats=None, max_parallel=None, warmup_queries=0, realtime=False, verbose=True,
+            trace=None):
+    """reference imitate_episodes.py:228-526, batched + sharded.  Returns (success_rate, avg_return)."""
+    set_seed(1000)
+    ckpt_dir = config["ckpt_dir"]
+    state_dim = config["state_dim"]
+    policy_class = config["policy_class"]
+    policy_config = config["policy_config"]
+    camera_names = config["camera_names"]
+    max_timesteps = int(config["episode_len"])
+    task_name = config["task_name"]
+    temporal_agg = config["temporal_agg"]
+    rank, world, _ = dist_utils.init_from_env()
+    on_gpu = torch.cuda.is_available()
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+
+    if policy is None:
+        policy = make_policy(policy_class, policy_config)
+        ckpt_path = os.path.join(ckpt_dir, ckpt_name)
+        if os.path.isfile(ckpt_path):
+            loading_status = policy.deserialize(torch.load(ckpt_path, weights_only=True))
+            if verbose:
+                print(loading_status)
+        elif verbose:
+            print(f"no checkpoint at {ckpt_path}: evaluating the random-init policy")
+        policy.cuda()
+        policy.eval()
+    if stats is None:
+        stats_path = os.path.join(ckpt_dir, "dataset_stats.pkl")
+        if os.path.isfile(stats_path):
+            with open(stats_path, "rb") as f:
+                stats = pickle.load(f)               # written by this program's own main()
+        else:
+            stats = _default_stats(state_dim)
+    pre_process = lambda s_qpos: (s_qpos - stats["qpos_mean"]) / stats["qpos_std"]          # noqa: E731
+    post_process = lambda a: a * stats["action_std"] + stats["action_mean"]                  # noqa: E731
+
+    num_queries = policy_config["num_queries"]
+    query_frequency = 1 if temporal_agg else num_queries
+    action_dim = policy_config.get("action_dim", 16)
+    if ensemble_factory is None:
+        from actmi.ops import TemporalEnsemble
+        ensemble_factory = lambda E: TemporalEnsemble(E, num_queries, action_dim, 0.01, dev)   # noqa: E731
+    if env_factory is None:
+        from actmi.envs import make_sim_env
+        env_factory = lambda pose, idx: make_sim_env(task_name, camera_names, pose, seed=idx)  # noqa: E731
+
+    # poses in the reference's draw order, then this rank's contiguous shard
+    poses = draw_episode_poses(task_name, num_rollouts, seed=1000)
+    lo, hi = shard_range(num_rollouts, rank, world)
+    counts = [shard_range(num_rollouts, r, world)[1] - shard_range(num_rollouts, r, world)[0] for r in range(world)]
+    if max_parallel is None:
+        max_parallel = getattr(getattr(policy, "model", None), "max_batch", None) or (hi - lo) or 1
+
+    local_results = []
+    env_max_reward = None
+    DT = 1 / FPS
+    t_policy, n_queries = 0.0, 0
+    pool = ThreadPoolExecutor(max_workers=min(16, max(1, max_parallel)))
+    for w0 in range(lo, hi, max_parallel):
+        ids = list(range(w0, min(hi, w0 + max_parallel)))
+        E = len(ids)
+        envs = [env_factory(poses[i], i) for i in ids]
+        env_max_reward = envs[0].task.max_reward
+        ts_list = list(pool.map(lambda e: e.reset(), envs))
+        ens = ensemble_factory(E) if temporal_agg else None
+        rewards = [[] for _ in range(E)]
+        pinned, all_actions = None, None
+        time0 = time.time()
+        for t in range(max_timesteps):
+            time1 = time.time()
+            qpos_numpy = np.stack([np.array(ts.observation["qpos"]) for ts in ts_list])
+            qpos = torch.from_numpy(pre_process(qpos_numpy)).float().to(dev)
+            if t % query_frequency == 0:
+                pinned = get_image_batch_u8(ts_list, camera_names, pinned)
+                curr_image = pinned.to(dev, non_blocking=True)
+                if t == 0:
+                    for _ in range(warmup_queries):
+                        policy(qpos, curr_image)
+                tq = time.time()
+                all_actions = policy(qpos, curr_image)                       # [E,Q,A]
+                n_queries += E
+            if temporal_agg:
+                raw_action = ens.step(all_actions)                           # [E,A] float64, like the reference
+            else:
+                raw_action = all_actions[:, t % query_frequency]
+            raw_action = raw_action.cpu().numpy()                            # D2H sync, once per step for all E
+            if t % query_frequency == 0:
+                t_policy += time.time() - tq
+            if trace is not None:
+                trace.append((ids, t, raw_action.copy()))
+            action = post_process(raw_action)
+            target_qpos = action[:, :-2]
+            ts_list = list(pool.map(lambda p: p[0].step(p[1]), zip(envs, target_qpos)))
+            for e in range(E):
+                rewards[e].append(ts_list[e].reward)
+            if realtime:
+                time.sleep(max(0, DT - (time.time() - time1)))
+        if verbose:
+            print(f"rank {rank}: episodes {ids[0]}..{ids[-1]} avg fps {max_timesteps / (time.time() - time0):.1f} "
+                  f"({E} parallel episodes)")
+        for e, i in enumerate(ids):
+            r = np.array(rewards[e])
+            episode_return = float(np.sum(r[r != None]))                      # noqa: E711  (reference :499)
+            local_results.append([episode_return, float(np.max(r))])
+    pool.shutdown()
+
+    local = torch.tensor(local_results, dtype=torch.float32).reshape(-1, 2)
+    allr = dist_utils.all_gather_rows(local, counts).numpy()                 # the ONE collective of the path
+    episode_returns, highest_rewards = allr[:, 0], allr[:, 1]
+    success_rate = float(np.mean(highest_rewards == env_max_reward))
+    avg_return = float(np.mean(episode_returns))
+    summary_str = f"\nSuccess rate: {success_rate}\nAverage return: {avg_return}\n\n"
+    for r in range(env_max_reward + 1):
+        more_or_equal_r = int((highest_rewards >= r).sum())
+        summary_str += f"Reward >= {r}: {more_or_equal_r}/{num_rollouts} = {more_or_equal_r / num_rollouts * 100}%\n"
+    if rank == 0:
+        if verbose:
+            print(summary_str)
+            if n_queries:
+                print(f"policy queries: {n_queries} in {t_policy:.2f} s on rank 0 = {n_queries / max(t_policy, 1e-9):.1f} steps/s")
+        os.makedirs(ckpt_dir, exist_ok=True)
+        result_file_name = "result_" + ckpt_name.split(".")[0] + ".txt"
+        with open(os.path.join(ckpt_dir, result_file_name), "w") as f:
+            f.write(summary_str)
+            f.write(repr(episode_returns.tolist()))
+            f.write("\n\n")
+            f.write(repr(highest_rewards.tolist()))
+    return success_rate, avg_return
+
+
+def forward_pass(data, policy):
+    """reference imitate_episodes.py:529-532."""
+    image_data, qpos_data, action_data, is_pad = data
+    image_data, qpos_data, action_data, is_pad = image_data.cuda(), qpos_data.cuda(), action_data.cuda(), is_pad.cuda()
+    return policy(qpos_data, image_data, action_data, is_pad)
+
+
+def train_bc(train_dataloader, val_dataloader, config, log=None):
+    """reference imitate_episodes.py:535-622 (wandb replaced by an optional ``log(dict, step)`` callable)."""
+    num_steps = config["num_steps"]
+    ckpt_dir = config["ckpt_dir"]
+    seed = config["seed"]
+    policy_class = config["policy_class"]
+    policy_config = config["policy_config"]
+    validate_every = config["validate_every"]
+    save_every = config["save_every"]
+    set_seed(seed)
+    policy = make_policy(policy_class, policy_config)
+    if config.get("resume_ckpt_path"):
+        loading_status = policy.deserialize(torch.load(config["resume_ckpt_path"], weights_only=True))
+        print(f'Resume policy from: {config["resume_ckpt_path"]}, Status: {loading_status}')
+    policy.cuda()
+    optimizer = make_optimizer(policy_class, policy)
+    min_val_loss = np.inf
+    best_ckpt_info = None
+    os.makedirs(ckpt_dir, exist_ok=True)
+    train_dataloader = repeater(train_dataloader)
+    for step in range(num_steps + 1):
+        if step % validate_every == 0:
+            policy.eval()
+            validation_dicts = []
+            for batch_idx, data in enumerate(val_dataloader):
+                validation_dicts.append({k: v.detach().float().cpu() for k, v in forward_pass(data, policy).items()})
+                if batch_idx > 50:
+                    break
+            validation_summary = compute_dict_mean(validation_dicts)
+            epoch_val_loss = float(validation_summary["loss"])
+            if epoch_val_loss < min_val_loss:
+                min_val_loss = epoch_val_loss
+                best_ckpt_info = (step, min_val_loss, deepcopy(policy.serialize()))
+            if log:
+                log({f"val_{k}": float(v) for k, v in validation_summary.items()}, step)
+            print(f"Val loss:   {epoch_val_loss:.5f}")
+        policy.train()
+        optimizer.zero_grad()
+        data = next(train_dataloader)
+        forward_dict = forward_pass(data, policy)
+        loss = forward_dict["loss"]
+        loss.backward()
+        optimizer.step()
+        if log:
+            log({k: float(v) for k, v in forward_dict.items()}, step)
+        if step % save_every == 0:
+            torch.save(policy.serialize(), os.path.join(ckpt_dir, f"policy_step_{step}_seed_{seed}.ckpt"))
+    torch.save(policy.serialize(), os.path.join(ckpt_dir, "policy_last.ckpt"))
+    best_step, min_val_loss, best_state_dict = best_ckpt_info
+    torch.save(best_state_dict, os.path.join(ckpt_dir, f"policy_step_{best_step}_seed_{seed}.ckpt"))
+    print(f"Training finished:\nSeed {seed}, val loss {min_val_loss:.6f} at step {best_step}")
+    return best_ckpt_info
+
+
+def repeater(data_loader):
+    """reference imitate_episodes.py:624-630."""
+    epoch = 0
+    for loader in repeat(data_loader):
+        for data in loader:
+            yield data
+        print(f"Epoch {epoch} done")
+        epoch += 1
+
+
+def build_config(args):
+    """The config dict of reference main() (:37-143)."""
+    task_name = args["task_name"]
+    task_config = SIM_TASK_CONFIGS[task_name]
+    camera_names = task_config["camera_names"]
+    policy_config = {"lr": args["lr"], "num_queries": args["chunk_size"], "kl_weight": args["kl_weight"],
+                     "hidden_dim": args["hidden_dim"], "dim_feedforward": args["dim_feedforward"], "lr_backbone": 1e-5,
+                     "backbone": "resnet18", "enc_layers": 4, "dec_layers": 7, "nheads": 8,
+                     "camera_names": camera_names, "vq": args.get("use_vq", False), "vq_class": args.get("vq_class"),
+                     "vq_dim": args.get("vq_dim"), "action_dim": 16, "no_encoder": args.get("no_encoder", False),
+                     "state_dim": 14, "max_batch": args.get("max_batch") or args["batch_size"]}
+    return {"num_steps": args["num_steps"], "eval_every": args["eval_every"], "validate_every": args["validate_every"],
+            "save_every": args["save_every"], "ckpt_dir": args["ckpt_dir"], "resume_ckpt_path": args.get("resume_ckpt_path"),
+            "episode_len": task_config["episode_len"], "state_dim": 14, "lr": args["lr"],
+            "policy_class": args["policy_class"], "onscreen_render": args.get("onscreen_render", False),
+            "policy_config": policy_config, "task_name": task_name, "seed": args["seed"],
+            "temporal_agg": args["temporal_agg"], "camera_names": camera_names, "real_robot": False,
+            "load_pretrain": False}
+
+
+def main(args):
+    set_seed(1)
+    config = build_config(args)
+    os.makedirs(config["ckpt_dir"], exist_ok=True)
+    with open(os.path.join(config["ckpt_dir"], "config.pkl"), "wb") as f:
+        pickle.dump(config, f)
+    if args["eval"]:
+        results = []
+        for ckpt_name in ["policy_last.ckpt"]:
+            success_rate, avg_return = eval_bc(config, ckpt_name, save_episode=True, num_rollouts=args["num_rollouts"])
+            results.append([ckpt_name, success_rate, avg_return])
+        for ckpt_name, success_rate, avg_return in results:
+            print(f"{ckpt_name}: {success_rate=} {avg_return=}")
+        return results
+    from actmi.config import ACTConfig
+    from actmi.envs import SyntheticDataset
+    cfg = ACTConfig.from_policy_config(config["policy_config"])
+    train_dl = SyntheticDataset(cfg, args["batch_size"], 8, seed=args["seed"])
+    val_dl = SyntheticDataset(cfg, args["batch_size"], 2, seed=args["seed"] + 1)
+    with open(os.path.join(config["ckpt_dir"], "dataset_stats.pkl"), "wb") as f:
+        pickle.dump(_default_stats(14), f)
+    best_step, min_val_loss, best_state_dict = train_bc(train_dl, val_dl, config)
+    torch.save(best_state_dict, os.path.join(config["ckpt_dir"], "policy_best.ckpt"))
+    print(f"Best ckpt, val loss {min_val_loss:.6f} @ step{best_step}")
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--eval", action="store_true")
+    parser.add_argument("--onscreen_render", action="store_true")
+    parser.add_argument("--ckpt_dir", action="store", type=str, required=True)
+    parser.add_argument("--policy_class", action="store", type=str, required=True)
+    parser.add_argument("--task_name", action="store", type=str, required=True)
+    parser.add_argument("--batch_size", action="store", type=int, required=True)
+    parser.add_argument("--seed", action="store", type=int, required=True)
+    parser.add_argument("--num_steps", action="store", type=int, required=True)
+    parser.add_argument("--lr", action="store", type=float, required=True)
+    parser.add_argument("--load_pretrain", action="store_true", default=False)
+    parser.add_argument("--eval_every", action="store", type=int, default=500)
+    parser.add_argument("--validate_every", action="store", type=int, default=500)
+    parser.add_argument("--save_every", action="store", type=int, default=500)
+    parser.add_argument("--resume_ckpt_path", action="store", type=str)
+    parser.add_argument("--skip_mirrored_data", action="store_true")
+    parser.add_argument("--kl_weight", action="store", type=int)
+    parser.add_argument("--chunk_size", action="store", type=int)
+    parser.add_argument("--hidden_dim", action="store", type=int)
+    parser.add_argument("--dim_feedforward", action="store", type=int)
+    parser.add_argument("--temporal_agg", action="store_true")
+    parser.add_argument("--use_vq", action="store_true")
+    parser.add_argument("--vq_class", action="store", type=int)
+    parser.add_argument("--vq_dim", action="store", type=int)
+    parser.add_argument("--no_encoder", action="store_true")
+    # additions (rollouts count hard-coded to 10 in the reference, :156)
+    parser.add_argument("--num_rollouts", action="store", type=int, default=50)
+    parser.add_argument("--max_batch", action="store", type=int, default=None)
+    main(vars(parser.parse_args()))
