@@ -127,6 +127,53 @@ class ACTEngine:
                                              C.c_void_p(out.data_ptr()), L.current_stream_ptr()), self.h, "forward_infer")
         return out
 
+    # ---- training -----------------------------------------------------------------------------
+    def forward_train(self, qpos, image, actions, is_pad, eps=None, dropout_p: float = 0.0, dropout_seed: int = 0):
+        """ACTPolicy.__call__ training branch (policy.py:288-320). Returns dict(l1, kl, loss, a_hat, mu, logvar) of
+        device tensors.  ``eps`` replaces the normal_() draw of reparametrize (detr_vae.py:19-22)."""
+        if not self._finalized:
+            self.finalize()
+        cfg = self.cfg
+        B = qpos.shape[0]
+        Q, A, Lz = cfg.num_queries, cfg.action_dim, cfg.latent_dim
+        qpos = qpos.to(torch.float32).contiguous()
+        image = image.contiguous()
+        fmt = self._image_fmt(image, B)
+        actions = actions[:, :Q].to(torch.float32).contiguous()          # policy.py:289-290
+        is_pad_u8 = is_pad[:, :Q].to(torch.uint8).contiguous()
+        if eps is None:
+            eps = torch.randn((B, Lz), dtype=torch.float32, device=qpos.device)
+        eps = eps.to(torch.float32).contiguous()
+        dev = qpos.device
+        losses = torch.empty(3, dtype=torch.float32, device=dev)
+        a_hat = torch.empty((B, Q, A), dtype=torch.float32, device=dev)
+        mu = torch.empty((B, Lz), dtype=torch.float32, device=dev)
+        logvar = torch.empty((B, Lz), dtype=torch.float32, device=dev)
+        self._keep = (qpos, image, actions, is_pad_u8, eps)               # the library reads qpos again in backward
+        L.check(self.lib.actmi_forward_train(
+            self.h, C.c_void_p(qpos.data_ptr()), C.c_void_p(image.data_ptr()), fmt, C.c_void_p(actions.data_ptr()),
+            C.c_void_p(is_pad_u8.data_ptr()), C.c_void_p(eps.data_ptr()), C.c_uint64(dropout_seed), float(dropout_p), B,
+            C.c_void_p(losses.data_ptr()), C.c_void_p(a_hat.data_ptr()), C.c_void_p(mu.data_ptr()),
+            C.c_void_p(logvar.data_ptr()), L.current_stream_ptr()), self.h, "forward_train")
+        return {"l1": losses[0], "kl": losses[1], "loss": losses[2], "a_hat": a_hat, "mu": mu, "logvar": logvar}
+
+    def backward(self, loss_scale: float = 1.0):
+        L.check(self.lib.actmi_backward(self.h, float(loss_scale), L.current_stream_ptr()), self.h, "backward")
+
+    def zero_grad(self):
+        L.check(self.lib.actmi_zero_grad(self.h, L.current_stream_ptr()), self.h, "zero_grad")
+
+    def adamw_step(self, lr, lr_backbone, weight_decay=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, step=1):
+        L.check(self.lib.actmi_adamw_step(self.h, lr, lr_backbone, weight_decay, beta1, beta2, eps, int(step),
+                                          L.current_stream_ptr()), self.h, "adamw_step")
+
+    def grad(self, key: str) -> torch.Tensor:
+        """Copy of the gradient of one state_dict entry (shape of the parameter)."""
+        p, n = C.c_void_p(), C.c_int64()
+        L.check(self.lib.actmi_grad_ptr(self.h, key.encode(), C.byref(p), C.byref(n)), self.h, f"grad_ptr({key})")
+        torch.cuda.synchronize()
+        return _from_ptr(p.value, n.value, self.device).clone().view(self.spec[key])
+
     # ---- debug --------------------------------------------------------------------------------
     def debug_stop_after(self, stage: str):
         L.check(self.lib.actmi_debug_stop_after(self.h, (stage or "").encode()), self.h, "debug_stop_after")

@@ -36,6 +36,12 @@ class GemmDesc(C.Structure):
         ("C", C.c_void_p), ("ldc", C.c_int64), ("rowmap", C.c_void_p),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("groups", C.c_int32),
         ("gA", C.c_int64), ("gB", C.c_int64), ("gSB", C.c_int64), ("gC", C.c_int64), ("gRes", C.c_int64),
+        ("ta", C.c_int32), ("tb", C.c_int32), ("a_rowmap", C.c_void_p),
+        ("B_add", C.c_void_p), ("ld_badd", C.c_int64), ("badd_mod", C.c_int32), ("splitk", C.c_int32),
+        ("mask", C.c_void_p), ("ldmask", C.c_int64), ("C2", C.c_void_p), ("scale2", C.c_void_p),
+        ("alpha", C.c_float), ("groups_inner", C.c_int32),
+        ("gA2", C.c_int64), ("gB2", C.c_int64), ("gC2", C.c_int64), ("gRes2", C.c_int64),
+        ("gMask", C.c_int64), ("gC2out", C.c_int64),
     ]
 
 

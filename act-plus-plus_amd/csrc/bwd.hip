@@ -1,0 +1,478 @@
+// Backward-pass kernels of the ACT training step that are not GEMM-shaped: LayerNorm, max-pool, softmax,
+// column sums (bias gradients), L1+KL loss, reparametrisation, fused multi-tensor AdamW.
+// Reference semantics: torch autograd of the modules in transformer.py / detr_vae.py / policy.py:288-320,
+// torch.optim.AdamW as configured at detr/main.py:102-110.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------- LayerNorm bwd
+constexpr int MAXV = 8;
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w;  dw += dy * xhat;  db += dy.
+// One wave per row, rows grid-strided; each wave keeps its dw/db partials in registers and adds them once.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ dy, const float* __restrict__ dx_add,
+                                                     float* __restrict__ dx, float* __restrict__ dw,
+                                                     float* __restrict__ db, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nw = gridDim.x * 4;
+    const int D4 = D >> 2;
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
+    f32x4 aw[MAXV], ab[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) { aw[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = aw[i]; }
+    const float invD = 1.f / (float)D;
+    for (int row = wid; row < M; row += nw) {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)row * D);
+        const f32x4* gr = reinterpret_cast<const f32x4*>(dy + (int64_t)row * D);
+        f32x4 v[MAXV], g[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D4) { v[i] = xr[c]; g[i] = gr[c]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+        }
+        const float mean = wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (lane + 64 * i < D4) { const f32x4 d = v[i] - mean; q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]); }
+        const float rstd = 1.f / sqrtf(wave_sum(q) * invD + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D4) {
+                const f32x4 xh = (v[i] - mean) * rstd;
+                const f32x4 gw = g[i] * w4[c];
+                aw[i] += g[i] * xh;
+                ab[i] += g[i];
+                v[i] = xh; g[i] = gw;
+                s1 += (gw[0] + gw[1]) + (gw[2] + gw[3]);
+                s2 += (gw[0] * xh[0] + gw[1] * xh[1]) + (gw[2] * xh[2] + gw[3] * xh[3]);
+            }
+        }
+        const float m1 = wave_sum(s1) * invD, m2 = wave_sum(s2) * invD;
+        f32x4* dr = reinterpret_cast<f32x4*>(dx + (int64_t)row * D);
+        const f32x4* ar = dx_add ? reinterpret_cast<const f32x4*>(dx_add + (int64_t)row * D) : nullptr;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D4) {
+                f32x4 o = (g[i] - m1 - v[i] * m2) * rstd;
+                if (ar) o += ar[c];
+                dr[c] = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(&dw[c * 4 + e], aw[i][e]);
+                atomicAdd(&db[c * 4 + e], ab[i][e]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- max-pool bwd
+// dx[pixel] = sum over the (<= 4) windows containing it of dy[window] where the window's FIRST maximum (scan order
+// r then s, strict '>', as ATen's max_pool2d) is this pixel.  Gather form: no atomics, bit-reproducible.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, int H, int W, int C4, int Ho, int Wo,
+                                                          int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        int64_t pix = idx / C4;
+        const int wi = (int)(pix % W); pix /= W;
+        const int hi = (int)(pix % H);
+        const int64_t img = pix / H;
+        const f32x4* xs = reinterpret_cast<const f32x4*>(x) + img * H * W * C4 + c4;
+        const f32x4* gs = reinterpret_cast<const f32x4*>(dy) + img * Ho * Wo * C4 + c4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int ho_lo = hi >> 1, ho_hi = (hi + 1) >> 1;      // windows with 2ho-1 <= hi <= 2ho+1
+        const int wo_lo = wi >> 1, wo_hi = (wi + 1) >> 1;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            if (ho >= Ho) continue;
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                if (wo >= Wo) continue;
+                f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int bpos[4] = {-1, -1, -1, -1};
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int h2 = 2 * ho - 1 + r;
+                    if ((unsigned)h2 >= (unsigned)H) continue;
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        const int w2 = 2 * wo - 1 + s;
+                        if ((unsigned)w2 >= (unsigned)W) continue;
+                        const f32x4 v = xs[((int64_t)h2 * W + w2) * C4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (v[e] > best[e] || bpos[e] < 0) { best[e] = v[e]; bpos[e] = h2 * W + w2; }
+                    }
+                }
+                const f32x4 g = gs[((int64_t)ho * Wo + wo) * C4];
+                const int me = hi * W + wi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (bpos[e] == me) acc[e] += g[e];
+            }
+        }
+        reinterpret_cast<f32x4*>(dx)[idx] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- column sums
+// out[n] += sum_m src[m][n]   (bias gradients; rows split over blockIdx.y, one atomic per column per block)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ src, int64_t ld, float* __restrict__ out,
+                                                     int M, int N, int rows_per_block) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int m0 = blockIdx.y * rows_per_block;
+    const int m1 = (m0 + rows_per_block < M) ? m0 + rows_per_block : M;
+    float acc = 0.f;
+    for (int m = m0; m < m1; ++m) acc += src[(int64_t)m * ld + n];
+    atomicAdd(&out[n], acc);
+}
+
+// dst[r][d] (+)= sum_b src[b*bs + r*ld + d]
+__global__ void sum_batch_kernel(const float* __restrict__ src, int64_t bs, int64_t ld, float* __restrict__ dst, int B,
+                                 int R, int D, int accumulate) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)R * D) return;
+    const int r = (int)(idx / D), d = (int)(idx - (int64_t)r * D);
+    float acc = accumulate ? dst[idx] : 0.f;
+    for (int b = 0; b < B; ++b) acc += src[(int64_t)b * bs + (int64_t)r * ld + d];
+    dst[idx] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------- attention bwd pieces
+// delta[b][h][q] = sum_d dO[b][q][h*HD+d] * O[b][q][h*HD+d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O,
+                                                         float* __restrict__ delta, int B, int H, int Nq, int HD) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // (b, q, h) flattened with h fastest
+    if (row >= (int64_t)B * Nq * H) return;
+    const int h = (int)(row % H);
+    const int64_t bq = row / H;
+    const float* a = dO + bq * (int64_t)H * HD + h * HD;
+    const float* o = O + bq * (int64_t)H * HD + h * HD;
+    float s = 0.f;
+    for (int d = lane; d < HD; d += 64) s += a[d] * o[d];
+    s = wave_sum(s);
+    if (lane == 0) {
+        const int64_t b = bq / Nq, q = bq - b * Nq;
+        delta[(b * H + h) * Nq + q] = s;
+    }
+}
+
+// P[g][q][k] = exp(S - lse[g][q]) (0 for masked / padded keys), in place; S was produced as scale * q.k
+__global__ void attn_probs_kernel(float* __restrict__ S, const float* __restrict__ lse, const uint8_t* __restrict__ kpm,
+                                  int64_t kpm_bs, int H, int Nq, int Nk, int ldp, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int k = (int)(idx % ldp);
+    const int64_t gq = idx / ldp;
+    const int64_t g = gq / Nq;
+    float v = 0.f;
+    if (k < Nk) {
+        const bool dead = kpm && kpm[(g / H) * kpm_bs + k] != 0;
+        if (!dead) v = expf(S[idx] - lse[gq]);
+    }
+    S[idx] = v;
+}
+
+// dS = P * (dP - delta[g][q]) * scale, in place of dP
+__global__ void attn_ds_kernel(const float* __restrict__ P, float* __restrict__ dP, const float* __restrict__ delta,
+                               float scale, int Nk, int ldp, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int k = (int)(idx % ldp);
+    const int64_t gq = idx / ldp;
+    dP[idx] = (k < Nk) ? P[idx] * (dP[idx] - delta[gq]) * scale : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------- losses
+// l1 = mean_{b,t,a} |actions - a_hat| * (1 - is_pad)   (policy.py:314-315: mean over ALL elements)
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ a_hat, const float* __restrict__ actions,
+                                                      const uint8_t* __restrict__ is_pad, float* __restrict__ losses,
+                                                      int A, int64_t total) {
+    float acc = 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x)
+        if (!is_pad[idx / A]) acc += fabsf(actions[idx] - a_hat[idx]);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&losses[0], acc / (float)total);
+}
+
+// kl = mean_b sum_d -0.5 (1 + logvar - mu^2 - exp(logvar))   (policy.py:386-387)
+__global__ void kl_loss_kernel(const float* __restrict__ latent_info, float* __restrict__ losses, int B, int L) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B * L; i += blockDim.x) {
+        const int b = i / L, d = i - b * L;
+        const float m = latent_info[b * 2 * L + d], lv = latent_info[b * 2 * L + L + d];
+        acc += -0.5f * (1.f + lv - m * m - expf(lv));
+    }
+    acc = wave_sum(acc);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) losses[1] = (part[0] + part[1] + part[2] + part[3]) / (float)B;
+}
+
+__global__ void loss_total_kernel(float* losses, float kl_weight) { losses[2] = losses[0] + losses[1] * kl_weight; }
+
+// d a_hat = sign(a_hat - actions) * (1 - is_pad) / (B*Q*A) * gscale
+__global__ void l1_bwd_kernel(const float* __restrict__ a_hat, const float* __restrict__ actions,
+                              const uint8_t* __restrict__ is_pad, float* __restrict__ d_a_hat, int A, int64_t total,
+                              float gscale) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    float g = 0.f;
+    if (!is_pad[idx / A]) {
+        const float d = a_hat[idx] - actions[idx];
+        g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * gscale / (float)total;
+    }
+    d_a_hat[idx] = g;
+}
+
+// z = mu + exp(logvar/2) * eps   (detr_vae.py:19-22)
+__global__ void reparam_kernel(const float* __restrict__ latent_info, const float* __restrict__ eps, float* __restrict__ z,
+                               float* __restrict__ mu_out, float* __restrict__ logvar_out, int B, int L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * L) return;
+    const int b = i / L, d = i - b * L;
+    const float m = latent_info[b * 2 * L + d], lv = latent_info[b * 2 * L + L + d];
+    z[i] = m + expf(lv * 0.5f) * eps[i];
+    if (mu_out) mu_out[i] = m;
+    if (logvar_out) logvar_out[i] = lv;
+}
+
+// d latent_info[b] = [ dz + klw*mu/B ,  dz*eps*0.5*exp(lv/2) + klw*(-0.5)(1 - exp(lv))/B ] * (gscale folded in dz / klw)
+__global__ void reparam_kl_bwd_kernel(const float* __restrict__ latent_info, const float* __restrict__ eps,
+                                      const float* __restrict__ dz, float* __restrict__ d_latent_info, int B, int L,
+                                      float klw_scaled) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * L) return;
+    const int b = i / L, d = i - b * L;
+    const float m = latent_info[b * 2 * L + d], lv = latent_info[b * 2 * L + L + d];
+    const float g = dz[i];
+    d_latent_info[b * 2 * L + d] = g + klw_scaled * m / (float)B;
+    d_latent_info[b * 2 * L + L + d] = g * eps[i] * 0.5f * expf(lv * 0.5f) + klw_scaled * (-0.5f) * (1.f - expf(lv)) / (float)B;
+}
+
+// ---------------------------------------------------------------------------------------------- AdamW
+// torch.optim.AdamW (single-tensor formulation) over the whole parameter arena.  group[chunk] per 64-float slot:
+// 0 = frozen/buffer/no-grad (skipped entirely, like params whose .grad is None), 1 = lr, 2 = lr_backbone.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    const uint8_t* __restrict__ group, int64_t n, float lr, float lr_bb,
+                                                    float wd, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint8_t gr = group[i >> 6];
+        if (!gr) continue;
+        const float l = gr == 2 ? lr_bb : lr;
+        float pi = p[i];
+        const float gi = g[i];
+        pi *= (1.f - l * wd);
+        const float mi = m[i] * b1 + gi * (1.f - b1);
+        const float vi = v[i] * b2 + gi * gi * (1.f - b2);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (l / bc1) * (mi / denom);
+    }
+}
+
+// [G][O][(r,s,c)] forward-packed conv weight -> [G][C][(r,s,o)] for the data gradient (n fastest in the contraction)
+__global__ void repack_dgrad_w_kernel(const float* __restrict__ wf, float* __restrict__ wd, int O, int I, int KK,
+                                      int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int o = (int)(idx % O);
+    int64_t rest = idx / O;
+    const int rs = (int)(rest % KK); rest /= KK;
+    const int c = (int)(rest % I);
+    const int64_t g = rest / I;
+    wd[idx] = wf[((g * O + o) * KK + rs) * I + c];
+}
+
+// wgrad comes out as [G][O][(r,s,c)]; the state_dict gradient is OIHW
+__global__ void unpack_wgrad_kernel(const float* __restrict__ gp, float* __restrict__ g_oihw, int O, int I, int KH, int KW,
+                                    int kpad, int ipack, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int s = (int)(idx % KW);
+    int64_t rest = idx / KW;
+    const int r = (int)(rest % KH); rest /= KH;
+    const int c = (int)(rest % I);
+    const int64_t o = rest / I;
+    g_oihw[idx] += gp[o * kpad + (r * KW + s) * ipack + c];      // accumulate like autograd
+}
+
+// y = x * (mask > 0) * scale[c]; also y_plain = x * (mask > 0)   (ReLU + FrozenBN backward on NHWC maps)
+__global__ void relu_bn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ add, const float* __restrict__ mask,
+                                   const float* __restrict__ scale, float* __restrict__ y_plain, float* __restrict__ y_scaled,
+                                   int C, int64_t per_group, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int64_t g = idx / per_group;
+    float v = x[idx] + (add ? add[idx] : 0.f);
+    if (mask && !(mask[idx] > 0.f)) v = 0.f;
+    if (y_plain) y_plain[idx] = v;
+    if (y_scaled) y_scaled[idx] = v * scale[g * C + c];
+}
+
+}  // namespace
+
+int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* dx_add, float* dx, float* dw, float* db,
+                  int M, int D, float eps, hipStream_t st) {
+    if ((D & 3) || D > 64 * 4 * MAXV) return -2;
+    if (M <= 0) return 0;
+    int blocks = (M + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    prof_begin("ln_bwd_kernel", 0.0, 4.0 * M * D * 3.0, st);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, x, w, dy, dx_add, dx, dw, db, M, D, eps);
+    prof_end(st);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_maxpool_bwd(const float* x, const float* dy, float* dx, int nimg, int H, int W, int C, int Ho, int Wo,
+                       hipStream_t st) {
+    if (C & 3) return -2;
+    const int64_t total = (int64_t)nimg * H * W * (C / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    prof_begin("maxpool_bwd_kernel", 0.0, 4.0 * nimg * C * (2.0 * H * W + (double)Ho * Wo), st);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, dy, dx, H, W, C / 4, Ho, Wo, total);
+    prof_end(st);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_colsum(const float* src, int64_t ld, float* out, int M, int N, hipStream_t st) {
+    if (M <= 0 || N <= 0) return 0;
+    int rpb = 256;
+    dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
+    prof_begin("colsum_kernel", 0.0, 4.0 * M * N, st);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, src, ld, out, M, N, rpb);
+    prof_end(st);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_sum_batch(const float* src, int64_t bs, int64_t ld, float* dst, int B, int R, int D, int accumulate,
+                     hipStream_t st) {
+    const int64_t total = (int64_t)R * D;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(sum_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, bs, ld, dst, B, R, D,
+                       accumulate);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_attn_delta(const float* dO, const float* O, float* delta, int B, int H, int Nq, int HD, hipStream_t st) {
+    const int64_t rows = (int64_t)B * Nq * H;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, dO, O, delta, B, H, Nq, HD);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_attn_probs(float* S, const float* lse, const uint8_t* kpm, int64_t kpm_bs, int G, int H, int Nq, int Nk, int ldp,
+                      hipStream_t st) {
+    const int64_t total = (int64_t)G * Nq * ldp;
+    if (total <= 0) return 0;
+    prof_begin("attn_probs_kernel", 0.0, 8.0 * total, st);
+    hipLaunchKernelGGL(attn_probs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, S, lse, kpm, kpm_bs, H, Nq,
+                       Nk, ldp, total);
+    prof_end(st);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_attn_ds(const float* P, float* dP, const float* delta, float scale, int G, int Nq, int Nk, int ldp,
+                   hipStream_t st) {
+    const int64_t total = (int64_t)G * Nq * ldp;
+    if (total <= 0) return 0;
+    prof_begin("attn_ds_kernel", 0.0, 12.0 * total, st);
+    hipLaunchKernelGGL(attn_ds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, dP, delta, scale, Nk, ldp,
+                       total);
+    prof_end(st);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_losses(const float* a_hat, const float* actions, const uint8_t* is_pad, const float* latent_info, float* losses,
+                  int B, int Q, int A, int L, float kl_weight, hipStream_t st) {
+    if (hipMemsetAsync(losses, 0, 3 * sizeof(float), st) != hipSuccess) return -3;
+    const int64_t total = (int64_t)B * Q * A;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(l1_loss_kernel, dim3(blocks), dim3(256), 0, st, a_hat, actions, is_pad, losses, A, total);
+    if (latent_info) hipLaunchKernelGGL(kl_loss_kernel, dim3(1), dim3(256), 0, st, latent_info, losses, B, L);
+    hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, st, losses, kl_weight);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_l1_bwd(const float* a_hat, const float* actions, const uint8_t* is_pad, float* d_a_hat, int B, int Q, int A,
+                  float gscale, hipStream_t st) {
+    const int64_t total = (int64_t)B * Q * A;
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a_hat, actions, is_pad, d_a_hat,
+                       A, total, gscale);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_reparam(const float* latent_info, const float* eps, float* z, float* mu_out, float* logvar_out, int B, int L,
+                   hipStream_t st) {
+    hipLaunchKernelGGL(reparam_kernel, dim3((B * L + 255) / 256), dim3(256), 0, st, latent_info, eps, z, mu_out, logvar_out,
+                       B, L);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_reparam_kl_bwd(const float* latent_info, const float* eps, const float* dz, float* d_latent_info, int B, int L,
+                          float klw_scaled, hipStream_t st) {
+    hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3((B * L + 255) / 256), dim3(256), 0, st, latent_info, eps, dz, d_latent_info,
+                       B, L, klw_scaled);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_adamw(float* p, const float* g, float* m, float* v, const uint8_t* group, int64_t n, float lr, float lr_bb,
+                 float wd, float b1, float b2, float eps, int64_t step, hipStream_t st) {
+    const float bc1 = 1.f - powf(b1, (float)step);
+    const float bc2 = 1.f - powf(b2, (float)step);
+    prof_begin("adamw_kernel", 0.0, 28.0 * (double)n, st);
+    hipLaunchKernelGGL(adamw_kernel, dim3(256 * 8), dim3(256), 0, st, p, g, m, v, group, n, lr, lr_bb, wd, b1, b2, eps, bc1,
+                       sqrtf(bc2));
+    prof_end(st);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_repack_dgrad_w(const float* wf, float* wd, int G, int O, int I, int KK, hipStream_t st) {
+    const int64_t total = (int64_t)G * I * KK * O;
+    hipLaunchKernelGGL(repack_dgrad_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wf, wd, O, I, KK, total);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_unpack_wgrad(const float* gp, float* g_oihw, int O, int I, int KH, int KW, int kpad, int ipack, hipStream_t st) {
+    const int64_t total = (int64_t)O * I * KH * KW;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gp, g_oihw, O, I, KH, KW,
+                       kpad, ipack, total);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_relu_bn_bwd(const float* x, const float* add, const float* mask, const float* scale, float* y_plain,
+                       float* y_scaled, int G, int64_t per_group, int C, hipStream_t st) {
+    const int64_t total = (int64_t)G * per_group;
+    prof_begin("relu_bn_bwd_kernel", 0.0, 16.0 * total, st);
+    hipLaunchKernelGGL(relu_bn_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, add, mask, scale,
+                       y_plain, y_scaled, C, per_group, total);
+    prof_end(st);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -74,18 +74,29 @@ int actmi_forward_infer(actmi_handle h, const float* qpos, const void* image, in
     return engine_forward_infer(h, qpos, image, image_fmt, B, a_hat, S(stream));
 }
 
-int actmi_forward_train(actmi_handle h, const float*, const void*, int, const float*, const uint8_t*, const float*,
-                        uint64_t, float, int, float*, float*, float*, float*, void*) {
+int actmi_forward_train(actmi_handle h, const float* qpos, const void* image, int image_fmt, const float* actions,
+                        const uint8_t* is_pad, const float* eps, uint64_t dropout_seed, float dropout_p, int B, float* losses,
+                        float* a_hat, float* mu, float* logvar, void* stream) {
     if (!h) return ACTMI_E_INVALID;
-    return bad(h, "training path not built in this version", ACTMI_E_STATE);
+    if (!qpos || !image || !actions || !is_pad) return bad(h, "null pointer");
+    return train_forward(h, qpos, image, image_fmt, actions, is_pad, eps, dropout_seed, dropout_p, B, losses, a_hat, mu, logvar,
+                         S(stream));
 }
-int actmi_backward(actmi_handle h, float, void*) { return h ? bad(h, "training path not built", ACTMI_E_STATE) : ACTMI_E_INVALID; }
-int actmi_zero_grad(actmi_handle h, void*) { return h ? bad(h, "training path not built", ACTMI_E_STATE) : ACTMI_E_INVALID; }
-int actmi_adamw_step(actmi_handle h, float, float, float, float, float, float, int64_t, void*) {
-    return h ? bad(h, "training path not built", ACTMI_E_STATE) : ACTMI_E_INVALID;
+int actmi_backward(actmi_handle h, float loss_scale, void* stream) { return h ? train_backward(h, loss_scale, S(stream)) : ACTMI_E_INVALID; }
+int actmi_zero_grad(actmi_handle h, void* stream) { return h ? train_zero_grad(h, S(stream)) : ACTMI_E_INVALID; }
+int actmi_adamw_step(actmi_handle h, float lr, float lr_backbone, float weight_decay, float beta1, float beta2, float eps,
+                     int64_t step, void* stream) {
+    return h ? train_adamw_step(h, lr, lr_backbone, weight_decay, beta1, beta2, eps, step, S(stream)) : ACTMI_E_INVALID;
 }
-int actmi_grad_ptr(actmi_handle h, const char*, void**, int64_t*) {
-    return h ? bad(h, "training path not built", ACTMI_E_STATE) : ACTMI_E_INVALID;
+int actmi_grad_ptr(actmi_handle h, const char* key, void** dev_ptr, int64_t* numel) {
+    if (!h || !key) return ACTMI_E_INVALID;
+    if (!h->train) return bad(h, "handle was created without enable_training", ACTMI_E_STATE);
+    auto it = h->index.find(key);
+    if (it == h->index.end()) return bad(h, std::string("unknown state_dict key: ") + key);
+    const Param& p = h->params[it->second];
+    if (dev_ptr) *dev_ptr = h->train->gbase + p.off;
+    if (numel) *numel = p.numel;
+    return 0;
 }
 
 int actmi_ensemble_step(float* ring, int32_t* tcount, const float* chunk, double k, double* out, uint8_t* populated, int E,

@@ -64,3 +64,39 @@ int launch_build_rowmap(int* map, int B, int C, int fh, int fw, int N, hipStream
 bool prof_enabled();
 void prof_begin(const char* name, double flops, double bytes, hipStream_t st);
 void prof_end(hipStream_t st);
+
+// ---- backward-pass kernels (bwd.hip, misc.hip) ---------------------------------------------------------
+int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* dx_add, float* dx, float* dw, float* db,
+                  int M, int D, float eps, hipStream_t st);
+int launch_maxpool_bwd(const float* x, const float* dy, float* dx, int nimg, int H, int W, int C, int Ho, int Wo,
+                       hipStream_t st);
+int launch_colsum(const float* src, int64_t ld, float* out, int M, int N, hipStream_t st);
+int launch_sum_batch(const float* src, int64_t bs, int64_t ld, float* dst, int B, int R, int D, int accumulate,
+                     hipStream_t st);
+int launch_attn_delta(const float* dO, const float* O, float* delta, int B, int H, int Nq, int HD, hipStream_t st);
+int launch_attn_probs(float* S, const float* lse, const uint8_t* kpm, int64_t kpm_bs, int G, int H, int Nq, int Nk, int ldp,
+                      hipStream_t st);
+int launch_attn_ds(const float* P, float* dP, const float* delta, float scale, int G, int Nq, int Nk, int ldp,
+                   hipStream_t st);
+int launch_losses(const float* a_hat, const float* actions, const uint8_t* is_pad, const float* latent_info, float* losses,
+                  int B, int Q, int A, int L, float kl_weight, hipStream_t st);
+int launch_bcast_add_rows(float* dst, const float* vec, int R, int D, hipStream_t st);
+int launch_l1_bwd(const float* a_hat, const float* actions, const uint8_t* is_pad, float* d_a_hat, int B, int Q, int A,
+                  float gscale, hipStream_t st);
+int launch_reparam(const float* latent_info, const float* eps, float* z, float* mu_out, float* logvar_out, int B, int L,
+                   hipStream_t st);
+int launch_reparam_kl_bwd(const float* latent_info, const float* eps, const float* dz, float* d_latent_info, int B, int L,
+                          float klw_scaled, hipStream_t st);
+int launch_adamw(float* p, const float* g, float* m, float* v, const uint8_t* group, int64_t n, float lr, float lr_bb,
+                 float wd, float b1, float b2, float eps, int64_t step, hipStream_t st);
+int launch_repack_dgrad_w(const float* wf, float* wd, int G, int O, int I, int KK, hipStream_t st);
+int launch_unpack_wgrad(const float* gp, float* g_oihw, int O, int I, int KH, int KW, int kpad, int ipack, hipStream_t st);
+int launch_relu_bn_bwd(const float* x, const float* add, const float* mask, const float* scale, float* y_plain,
+                       float* y_scaled, int G, int64_t per_group, int C, hipStream_t st);
+int launch_normalize_pad(const void* image, int fmt, const float* lut, float* out, int B, int C, int H, int W,
+                         hipStream_t st);
+int launch_gather_rows(const float* src, const int* map, float* dst, int M, int D, hipStream_t st);
+int launch_small_linear_wgrad(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dW, int M, int N, int K,
+                              hipStream_t st);
+int launch_cvae_maps(int* map, uint8_t* kpm, const uint8_t* is_pad, int B, int Q, hipStream_t st);
+int launch_axpy(float* dst, const float* src, int64_t n, hipStream_t st);

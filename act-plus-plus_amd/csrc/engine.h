@@ -30,6 +30,37 @@ struct DecW { MhaW self_attn, cross; float *l1w, *l1b, *l2w, *l2b, *n1w, *n1b, *
 
 struct DbgView { const float* ptr; int64_t numel; };
 
+// saved activations of one encoder layer (training)
+struct EncSave { float *x_in, *QKV, *lse, *ATT, *Y1, *X1, *Hb, *Y2; };
+struct BlockSave { int c1, c2, ds; float *y1, *out; };
+
+struct TrainState {
+    int B = 0, fmt = 0;
+    bool have_forward = false;
+    const float* qpos = nullptr;
+    float *gbase = nullptr, *mbase = nullptr, *vbase = nullptr;
+    uint8_t* group = nullptr;
+    // backbone
+    float *xn4 = nullptr, *pool = nullptr, *g_act1 = nullptr, *gbuf[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* conv1_gw = nullptr;
+    std::vector<BlockSave> blocks;
+    std::vector<float*> conv_gw, conv_wd;
+    // transformer
+    std::vector<EncSave> en, cv;
+    float *mem = nullptr, *Xc = nullptr, *cv_out = nullptr;
+    int* cmap = nullptr;
+    uint8_t* ckpm = nullptr;
+    float *latent_info = nullptr, *z = nullptr, *eps = nullptr, *d_latent_info = nullptr, *dz = nullptr;
+    float *sa_tmp = nullptr, *t1 = nullptr, *qin = nullptr, *dq = nullptr, *KV = nullptr, *lse_c = nullptr, *Oc = nullptr,
+          *Y2pre = nullptr, *T2 = nullptr, *Hd = nullptr, *Y3pre = nullptr, *T3 = nullptr, *hs = nullptr, *a_hat = nullptr,
+          *actions = nullptr, *losses = nullptr;
+    uint8_t* is_pad = nullptr;
+    // backward scratch
+    float *gA = nullptr, *gB = nullptr, *gC = nullptr, *gH = nullptr, *gQKV = nullptr, *Pbuf = nullptr, *dPbuf = nullptr,
+          *delta = nullptr, *dXg = nullptr, *tmp2BD = nullptr, *tmpD = nullptr, *dqb = nullptr;
+    int* pos_rows = nullptr;
+};
+
 struct actmi_ctx {
     actmi_config cfg;
     std::string err;
@@ -55,6 +86,7 @@ struct actmi_ctx {
     float *dO = nullptr, *dY = nullptr, *dT2 = nullptr, *dH = nullptr, *hs = nullptr;
     std::map<std::string, DbgView> dbg;
     std::string stop_stage;   // debug: return from the forward right after this stage
+    TrainState* train = nullptr;
 
     float* P(const std::string& key);
 };
@@ -63,5 +95,14 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out);
 int engine_destroy(actmi_ctx* ctx);
 const char* engine_create_error();
 int engine_finalize(actmi_ctx* ctx, hipStream_t st);
+int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st);
+int train_create(actmi_ctx* ctx);
+int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt, const float* actions, const uint8_t* is_pad,
+                  const float* eps, uint64_t dropout_seed, float dropout_p, int B, float* losses, float* a_hat_out,
+                  float* mu_out, float* logvar_out, hipStream_t st);
+int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st);
+int train_zero_grad(actmi_ctx* ctx, hipStream_t st);
+int train_adamw_step(actmi_ctx* ctx, float lr, float lr_backbone, float wd, float b1, float b2, float eps, int64_t step,
+                     hipStream_t st);
 int engine_forward_infer(actmi_ctx* ctx, const float* qpos, const void* image, int fmt, int B, float* a_hat,
                          hipStream_t st);

@@ -299,6 +299,7 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
     if ((rc = dev_alloc(ctx, &ctx->dH, BQ * F))) return fail(rc);
     if ((rc = dev_alloc(ctx, &ctx->hs, BQ * D))) return fail(rc);
     ctx->finalized = false;
+    if (g.enable_training && (rc = train_create(ctx))) return fail(rc);
     *out = ctx;
     return 0;
 }
@@ -306,6 +307,7 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
 int engine_destroy(actmi_ctx* ctx) {
     if (!ctx) return 0;
     for (void* p : ctx->allocs) (void)hipFree(p);
+    delete ctx->train;
     delete ctx;
     return 0;
 }
@@ -316,11 +318,11 @@ const char* engine_create_error() { return g_create_error.c_str(); }
 // finalize: weight preparation
 // ------------------------------------------------------------------------------------------------
 
-int engine_finalize(actmi_ctx* ctx, hipStream_t st) {
-    ctx->err.clear();
+// device-side weight preparation; runs at finalize and after every optimizer step (all asynchronous on `st`)
+int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st) {
     const actmi_config& g = ctx->cfg;
     const int C = g.num_cams, w0 = g.base_width, D = g.hidden_dim, Q = g.num_queries;
-    // 1. conv weights OIHW -> [cam][O][(r,s,c)], FrozenBN -> scale/bias
+    // conv weights OIHW -> [cam][O][(r,s,c)], FrozenBN -> scale/bias
     for (int cam = 0; cam < C; ++cam) {
         std::string p = "backbones." + std::to_string(cam) + ".0.body.";
         CHK(launch_repack_conv_w(ctx->P(p + "conv1.weight"), ctx->conv1_w + (int64_t)cam * w0 * 148, 1, w0, 3, 7, 7, 0, 0,
@@ -335,6 +337,27 @@ int engine_finalize(actmi_ctx* ctx, hipStream_t st) {
                                cl.cout, st));
         }
     }
+    // learned rows of the token position table (transformer.py:91-92)
+    HIPCHK(hipMemcpyAsync(ctx->pos_tokens, ctx->P("additional_pos_embed.weight"), 2 * D * sizeof(float),
+                          hipMemcpyDeviceToDevice, st));
+    // decoder layer 0, constant part: tgt = 0 => self-attention output is
+    // out_proj(b_v) + b_o for every query; t1 = norm1 of it; q = (t1 + query_embed) Wq^T + bq.
+    {
+        const DecW& d = ctx->dec[0];
+        GemmArgs a = linear_args(d.self_attn.in_b + 2 * D, D, 1, D, d.self_attn.out_w, D, d.self_attn.out_b, ctx->tmp_vec, D);
+        CHK(launch_gemm(a, st, &ctx->err));
+        CHK(launch_layernorm(ctx->tmp_vec, nullptr, 0, d.n1w, d.n1b, nullptr, nullptr, ctx->dec_t1, 1, D, 1e-5f, st, &ctx->err));
+        GemmArgs q = linear_args(ctx->P("query_embed.weight"), D, Q, D, d.cross.in_w, D, d.cross.in_b, ctx->dec_q, D);
+        q.A_add = ctx->dec_t1; q.ld_add = D; q.add_mod = 1; q.add_ncols = D;
+        CHK(launch_gemm(q, st, &ctx->err));
+    }
+    return 0;
+}
+
+int engine_finalize(actmi_ctx* ctx, hipStream_t st) {
+    ctx->err.clear();
+    const actmi_config& g = ctx->cfg;
+    const int C = g.num_cams, D = g.hidden_dim;
     // 2. u8 -> normalised float LUT with the reference's arithmetic:
     //    x = float(v / 255.0 in f64)  (imitate_episodes.py:212), (x - mean) / std in f32 (policy.py:268-272)
     {
@@ -371,17 +394,7 @@ int engine_finalize(actmi_ctx* ctx, hipStream_t st) {
                 }
         HIPCHK(hipMemcpy(ctx->pos_tokens, pos.data(), pos.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    // 4. decoder layer 0, constant part: tgt = 0 => self-attention output is
-    //    out_proj(b_v) + b_o for every query; t1 = norm1 of it; q = (t1 + query_embed) Wq^T + bq.
-    {
-        const DecW& d = ctx->dec[0];
-        GemmArgs a = linear_args(d.self_attn.in_b + 2 * D, D, 1, D, d.self_attn.out_w, D, d.self_attn.out_b, ctx->tmp_vec, D);
-        CHK(launch_gemm(a, st, &ctx->err));
-        CHK(launch_layernorm(ctx->tmp_vec, nullptr, 0, d.n1w, d.n1b, nullptr, nullptr, ctx->dec_t1, 1, D, 1e-5f, st, &ctx->err));
-        GemmArgs q = linear_args(ctx->P("query_embed.weight"), D, Q, D, d.cross.in_w, D, d.cross.in_b, ctx->dec_q, D);
-        q.A_add = ctx->dec_t1; q.ld_add = D; q.add_mod = 1; q.add_ncols = D;
-        CHK(launch_gemm(q, st, &ctx->err));
-    }
+    CHK(engine_prepare_weights(ctx, st));
     HIPCHK(hipStreamSynchronize(st));
     ctx->finalized = true;
     return 0;

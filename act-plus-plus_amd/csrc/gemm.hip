@@ -1,19 +1,22 @@
-// fp32 MFMA GEMM / implicit-GEMM convolution for gfx950 (v_mfma_f32_32x32x2_f32, exact f32).
+// fp32 MFMA GEMM / implicit-GEMM convolution for gfx950 (v_mfma_f32_32x32x2_f32, exact f32), forward and backward.
 //
-// One kernel serves every dense contraction of the ACT path: nn.Linear, the packed MHA in/out projections,
+// One kernel family serves every dense contraction of the ACT path: nn.Linear, the packed MHA in/out projections,
 // the FFN, the 1x1 input_proj and the 3x3 / 1x1-stride-2 ResNet convolutions as NHWC implicit im2col
-// (reference: detr/models/transformer.py:196-224, detr_vae.py:57-61,184; torchvision BasicBlock).
+// (reference: detr/models/transformer.py:196-224, detr_vae.py:57-61,184; torchvision BasicBlock), plus their
+// gradients: dX = dY W (B stored [contraction][out]), dW = dY^T X (both operands stored [contraction][out]), the
+// convolution data gradient (gather over (r,s,n)) and weight gradient (gather of X, split-K with float atomics),
+// and the batched products of the attention backward.
 //
 // Tiling (CDNA4, 64-wide waves): 256 threads = 4 waves, one per SIMD.  Block tile BMxBN, wave tile WMxWN made
-// of 32x32 MFMA tiles.  K is consumed 32 at a time through a double-buffered LDS stage.  Both operands are
-// "row-major with K contiguous" (A[m][k], W[n][k]); a 16-byte global chunk (4 consecutive k) is stored as
-// one float4 in LDS plane p = chunk index, row r:  lds[p][r].  The f32 MFMA takes ONE k per lane-half, and
-// the sum over k is order-free, so lane (i = lane&31, h = lane>>5) reads the float4 at plane 2*kb+h, row i
-// and feeds its 4 components to 4 consecutive MFMAs: A and B use the same (h, j) -> k assignment, so the
-// contraction is complete and no LDS transpose or shuffle is needed.  One ds_read_b128 per operand tile
-// feeds 4 MFMAs (256 SIMD cycles): LDS bandwidth is irrelevant, the kernel is MFMA-issue bound.
-// Planes are padded by one float4 so that the 8 lanes that write one row's 8 chunks hit 8 different
-// 16-byte bank groups (ds_write_b128 is serviced 8 lanes at a time).
+// of 32x32 MFMA tiles.  The contraction is consumed 32 at a time through a double-buffered LDS stage.  In LDS both
+// operands live as float4 "planes": plane p holds, for every out-row r, the 4 contraction values 4p..4p+3.
+// The f32 MFMA takes ONE k per lane-half and the sum over k is order-free, so lane (i = lane&31, h = lane>>5) reads
+// the float4 at plane 2*kb+h, row i and feeds its 4 components to 4 consecutive MFMAs: A and B use the same
+// (h, j) -> k assignment, so the contraction is complete and no LDS transpose or shuffle is needed.  One
+// ds_read_b128 per operand tile feeds 4 MFMAs (256 SIMD cycles): LDS bandwidth is irrelevant, the kernel is
+// MFMA-issue bound.  Operands stored contraction-contiguous are staged with one 16-byte global load per float4;
+// operands stored out-contiguous ([contraction][out]) are staged as 4x4 micro-tiles transposed in registers.
+// Planes are padded by one float4 so that the lanes writing one row's chunks hit different bank groups.
 #include "common.h"
 #include <cstdio>
 
@@ -22,16 +25,22 @@ namespace {
 constexpr int BK = 32;
 constexpr int NPL = BK / 4;
 
+enum { A_N = 0, A_CONV = 1, A_DGRAD = 2, A_T = 3 };
+enum { B_N = 0, B_T = 1, B_WGRAD = 2 };
+
 template <int BM, int BN>
 constexpr int stage_f4() { return NPL * ((BM + 1) + (BN + 1)); }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int PSA = BM + 1, PSB = BN + 1;
     constexpr int STAGE = stage_f4<BM, BN>();
-    constexpr int NLA = BM / 32, NLB = BN / 32;
+    constexpr int NLA = (AMODE == A_T) ? 4 : BM / 32;
+    constexpr int NLB = (BMODE != B_N) ? 4 : BN / 32;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f32x4* smem = reinterpret_cast<f32x4*>(smem_raw);
 
@@ -46,97 +55,239 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
     }
     const int m0 = (bid / tiles_n) * BM;
     const int n0 = (bid % tiles_n) * BN;
-    const int g = blockIdx.z;
+    const int splitk = p.splitk > 1 ? p.splitk : 1;
+    const int split = blockIdx.z % splitk;
+    const int g = blockIdx.z / splitk;
+    int64_t offA, offB, offC, offRes;
+    if (p.groups_inner > 0) {
+        const int g1 = g / p.groups_inner, g2 = g % p.groups_inner;
+        offA = g1 * p.gA + g2 * p.gA2; offB = g1 * p.gB + g2 * p.gB2;
+        offC = g1 * p.gC + g2 * p.gC2; offRes = g1 * p.gRes + g2 * p.gRes2;
+    } else {
+        offA = (int64_t)g * p.gA; offB = (int64_t)g * p.gB; offC = (int64_t)g * p.gC; offRes = (int64_t)g * p.gRes;
+    }
+    const float* __restrict__ A = p.A + offA;
+    const float* __restrict__ Bw = p.Bw + offB;
 
-    const float* __restrict__ A = p.A + (int64_t)g * p.gA;
-    const float* __restrict__ Bw = p.Bw + (int64_t)g * p.gB;
+    const int nk_total = (p.K + BK - 1) / BK;
+    const int tps = (nk_total + splitk - 1) / splitk;
+    const int kt_begin = split * tps;
+    const int kt_end = (kt_begin + tps < nk_total) ? kt_begin + tps : nk_total;
+    if (kt_begin >= kt_end) return;      // block-uniform
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wrow0 = (wave / WAVES_N) * WM;
     const int wcol0 = (wave % WAVES_N) * WN;
-    const int cidx = t & 7;          // which 16-byte chunk of the 32-wide k tile this thread stages
-    const int srow = t >> 3;         // staging row (plus 32*i)
+    const int cidx = t & 7;          // N-form staging: which 16-byte chunk of the 32-wide k tile
+    const int srow = t >> 3;         // N-form staging row (plus 32*i)
 
-    // ---- per-thread row descriptors (constant over the K loop)
+    // ------------------------------------------------------------------ A operand descriptors
     const float* a_ptr[NLA];
     const float* add_ptr[NLA];
     int a_hi0[NLA], a_wi0[NLA];
     bool a_ok[NLA];
-    const bool use_add = (MODE == 0) && p.A_add != nullptr && n0 < p.add_ncols;
+    const bool use_add = (AMODE == A_N) && p.A_add != nullptr && n0 < p.add_ncols;
+    // T-form micro tile of A: out group og (4 consecutive m), k group kg (4 consecutive k)
+    const int a_og = t % (BM / 4), a_kg = t / (BM / 4);
+    if (AMODE == A_T) {
+        // nothing per row: addresses are formed per k row in the loader
+    } else {
 #pragma unroll
-    for (int i = 0; i < NLA; ++i) {
-        const int m = m0 + srow + 32 * i;
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
-        if (MODE == 0) {
-            a_ptr[i] = A + (int64_t)mm * p.lda;
-            add_ptr[i] = use_add ? p.A_add + (int64_t)(mm % p.add_mod) * p.ld_add : nullptr;
-            a_hi0[i] = a_wi0[i] = 0;
-        } else {
-            const int hw = p.Ho * p.Wo;
-            const int b = mm / hw, rem = mm - b * hw;
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            a_ptr[i] = A + (int64_t)b * p.img_stride;
+        for (int i = 0; i < NLA; ++i) {
+            const int m = m0 + srow + 32 * i;
+            a_ok[i] = m < p.M;
+            const int mm = a_ok[i] ? m : 0;
             add_ptr[i] = nullptr;
-            a_hi0[i] = ho * p.stride - p.pad;
-            a_wi0[i] = wo * p.stride - p.pad;
+            a_hi0[i] = a_wi0[i] = 0;
+            if (AMODE == A_N) {
+                const int64_t ar = p.a_rowmap ? p.a_rowmap[mm] : mm;
+                a_ptr[i] = A + ar * p.lda;
+                if (use_add) add_ptr[i] = p.A_add + (int64_t)(mm % p.add_mod) * p.ld_add;
+            } else if (AMODE == A_CONV) {
+                const int hw = p.Ho * p.Wo;
+                const int b = mm / hw, rem = mm - b * hw;
+                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                a_ptr[i] = A + (int64_t)b * p.img_stride;
+                a_hi0[i] = ho * p.stride - p.pad;
+                a_wi0[i] = wo * p.stride - p.pad;
+            } else {   // A_DGRAD: rows are input pixels (b, hi, wi)
+                const int hw = p.H * p.W;
+                const int b = mm / hw, rem = mm - b * hw;
+                const int hi = rem / p.W, wi = rem - hi * p.W;
+                a_ptr[i] = A + (int64_t)b * p.img_stride;
+                a_hi0[i] = hi + p.pad;
+                a_wi0[i] = wi + p.pad;
+            }
         }
     }
+    // ------------------------------------------------------------------ B operand descriptors
     const float* b_ptr[NLB];
     bool b_ok[NLB];
+    const int b_og = t % (BN / 4), b_kg = t / (BN / 4);
+    int wg_r = 0, wg_s = 0, wg_c = 0;        // B_WGRAD: this thread's (r, s, c0) of its 4 out columns
+    if (BMODE == B_N) {
 #pragma unroll
-    for (int i = 0; i < NLB; ++i) {
-        const int n = n0 + srow + 32 * i;
-        b_ok[i] = n < p.N;
-        b_ptr[i] = Bw + (int64_t)(b_ok[i] ? n : 0) * p.ldb;
+        for (int i = 0; i < NLB; ++i) {
+            const int n = n0 + srow + 32 * i;
+            b_ok[i] = n < p.N;
+            b_ptr[i] = Bw + (int64_t)(b_ok[i] ? n : 0) * p.ldb;
+        }
+    } else if (BMODE == B_WGRAD) {
+        const int j0 = n0 + b_og * 4;
+        const int rs = j0 / p.Cin;
+        wg_c = j0 - rs * p.Cin;
+        wg_r = rs / p.KW;
+        wg_s = rs - wg_r * p.KW;
     }
 
     f32x4 ra[NLA], rb[NLB];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto load_tile = [&](int kt) {
-        const int k = kt * BK + cidx * 4;
-        const bool kok = k < p.K;
-        if (MODE == 0) {
+        // ---------------- A
+        if (AMODE == A_T) {
+            if (a_kg < NPL) {
+                const int o = m0 + a_og * 4;
 #pragma unroll
-            for (int i = 0; i < NLA; ++i) {
-                f32x4 v = zero4;
-                if (a_ok[i] && kok) {
-                    v = *reinterpret_cast<const f32x4*>(a_ptr[i] + k);
-                    if (use_add) v += *reinterpret_cast<const f32x4*>(add_ptr[i] + k);
+                for (int j = 0; j < 4; ++j) {
+                    const int kk = kt * BK + a_kg * 4 + j;
+                    f32x4 v = zero4;
+                    if (kk < p.K) {
+                        const float* src = A + (int64_t)kk * p.lda + o;
+                        if (o + 3 < p.M) v = ld4(src);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (o + e < p.M) v[e] = src[e];
+                        }
+                    }
+                    ra[j] = v;
                 }
-                ra[i] = v;
             }
         } else {
-            const int rs = k / p.Cin;
-            const int c = k - rs * p.Cin;
-            const int r = rs / p.KW;
-            const int s = rs - r * p.KW;
+            const int k = kt * BK + cidx * 4;
+            const bool kok = k < p.K;
+            if (AMODE == A_N) {
 #pragma unroll
-            for (int i = 0; i < NLA; ++i) {
-                const int hi = a_hi0[i] + r, wi = a_wi0[i] + s;
-                f32x4 v = zero4;
-                if (a_ok[i] && kok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                    v = *reinterpret_cast<const f32x4*>(a_ptr[i] + ((int64_t)hi * p.W + wi) * p.Cin + c);
-                ra[i] = v;
+                for (int i = 0; i < NLA; ++i) {
+                    f32x4 v = zero4;
+                    if (a_ok[i] && kok) {
+                        v = ld4(a_ptr[i] + k);
+                        if (use_add) v += ld4(add_ptr[i] + k);
+                    }
+                    ra[i] = v;
+                }
+            } else if (AMODE == A_CONV) {
+                const int rs = k / p.Cin;
+                const int c = k - rs * p.Cin;
+                const int r = rs / p.KW;
+                const int s = rs - r * p.KW;
+#pragma unroll
+                for (int i = 0; i < NLA; ++i) {
+                    const int hi = a_hi0[i] + r, wi = a_wi0[i] + s;
+                    f32x4 v = zero4;
+                    if (a_ok[i] && kok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                        v = ld4(a_ptr[i] + ((int64_t)hi * p.W + wi) * p.Cin + c);
+                    ra[i] = v;
+                }
+            } else {   // A_DGRAD: contraction (r, s, n) over the forward output channels
+                const int Cq = p.K / (p.KH * p.KW);
+                const int rs = k / Cq;
+                const int n = k - rs * Cq;
+                const int r = rs / p.KW;
+                const int s = rs - r * p.KW;
+#pragma unroll
+                for (int i = 0; i < NLA; ++i) {
+                    const int hn = a_hi0[i] - r, wn = a_wi0[i] - s;
+                    f32x4 v = zero4;
+                    if (a_ok[i] && kok && hn >= 0 && wn >= 0) {
+                        const int ho = hn / p.stride, wo = wn / p.stride;
+                        if (ho * p.stride == hn && wo * p.stride == wn && ho < p.Ho && wo < p.Wo)
+                            v = ld4(a_ptr[i] + ((int64_t)ho * p.Wo + wo) * Cq + n);
+                    }
+                    ra[i] = v;
+                }
             }
         }
+        // ---------------- B
+        if (BMODE == B_N) {
+            const int k = kt * BK + cidx * 4;
+            const bool kok = k < p.K;
 #pragma unroll
-        for (int i = 0; i < NLB; ++i) {
-            f32x4 v = zero4;
-            if (b_ok[i] && kok) v = *reinterpret_cast<const f32x4*>(b_ptr[i] + k);
-            rb[i] = v;
+            for (int i = 0; i < NLB; ++i) {
+                f32x4 v = zero4;
+                if (b_ok[i] && kok) v = ld4(b_ptr[i] + k);
+                rb[i] = v;
+            }
+        } else if (BMODE == B_T) {
+            if (b_kg < NPL) {
+                const int o = n0 + b_og * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kk = kt * BK + b_kg * 4 + j;
+                    f32x4 v = zero4;
+                    if (kk < p.K) {
+                        const float* src = Bw + (int64_t)kk * p.ldb + o;
+                        const float* ad = p.B_add ? p.B_add + (int64_t)(kk % p.badd_mod) * p.ld_badd + o : nullptr;
+                        if (o + 3 < p.N) {
+                            v = ld4(src);
+                            if (ad) v += ld4(ad);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (o + e < p.N) v[e] = src[e] + (ad ? ad[e] : 0.f);
+                        }
+                    }
+                    rb[j] = v;
+                }
+            }
+        } else {   // B_WGRAD: B[(r,s,c)][m] gathered from the forward conv's NHWC input
+            if (b_kg < NPL) {
+                const bool ook = (n0 + b_og * 4) < p.N;
+                const int hw = p.Ho * p.Wo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int mm = kt * BK + b_kg * 4 + j;
+                    f32x4 v = zero4;
+                    if (ook && mm < p.K) {
+                        const int b = mm / hw, rem = mm - b * hw;
+                        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                        const int hi = ho * p.stride - p.pad + wg_r, wi = wo * p.stride - p.pad + wg_s;
+                        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                            v = ld4(Bw + (int64_t)b * p.img_stride + ((int64_t)hi * p.W + wi) * p.Cin + wg_c);
+                    }
+                    rb[j] = v;
+                }
+            }
         }
     };
     auto store_tile = [&](int stage) {
         f32x4* sa = smem + stage * STAGE;
         f32x4* sb = sa + NPL * PSA;
+        if (AMODE == A_T) {
+            if (a_kg < NPL) {
 #pragma unroll
-        for (int i = 0; i < NLA; ++i) sa[cidx * PSA + srow + 32 * i] = ra[i];
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 v = {ra[0][i], ra[1][i], ra[2][i], ra[3][i]};
+                    sa[a_kg * PSA + a_og * 4 + i] = v;
+                }
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < NLB; ++i) sb[cidx * PSB + srow + 32 * i] = rb[i];
+            for (int i = 0; i < NLA; ++i) sa[cidx * PSA + srow + 32 * i] = ra[i];
+        }
+        if (BMODE == B_N) {
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) sb[cidx * PSB + srow + 32 * i] = rb[i];
+        } else {
+            if (b_kg < NPL) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 v = {rb[0][i], rb[1][i], rb[2][i], rb[3][i]};
+                    sb[b_kg * PSB + b_og * 4 + i] = v;
+                }
+            }
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -147,13 +298,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
+    load_tile(kt_begin);
     store_tile(0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        const bool more = kt + 1 < kt_end;
         if (more) load_tile(kt + 1);
         const f32x4* sa = smem + cur * STAGE;
         const f32x4* sb = sa + NPL * PSA;
@@ -179,40 +329,48 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
     // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const float* scale = p.scale ? p.scale + (int64_t)g * p.gSB : nullptr;
     const float* bias = p.bias ? p.bias + (int64_t)g * p.gSB : nullptr;
-    const float* res = p.res ? p.res + (int64_t)g * p.gRes : nullptr;
-    float* C = p.C + (int64_t)g * p.gC;
+    const float* res = p.res ? p.res + offRes : nullptr;
+    const float* mask = p.mask ? p.mask + (int64_t)g * p.gMask : nullptr;
+    const int64_t ldmask = p.ldmask ? p.ldmask : p.ldc;
+    float* C = p.C + offC;
+    float* C2 = p.C2 ? p.C2 + (int64_t)g * p.gC2out : nullptr;
+    const float alpha = p.alpha != 0.f ? p.alpha : 1.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wcol0 + j * 32 + li;
         const bool nok = n < p.N;
         const float sc = (scale && nok) ? scale[n] : 1.f;
         const float bi = (bias && nok) ? bias[n] : 0.f;
+        const float sc2 = (C2 && nok) ? p.scale2[(int64_t)g * p.gSB + n] : 1.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wrow0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (nok && m < p.M) {
-                    float v = acc[i][j][e];
+                    float v = acc[i][j][e] * alpha;
                     v = scale ? v * sc + bi : v + bi;
                     if (res) {
                         const int rm = p.res_mod ? (m % p.res_mod) : m;
                         v += res[(int64_t)rm * p.ldres + n];
                     }
+                    if (mask && !(mask[(int64_t)m * ldmask + n] > 0.f)) v = 0.f;
                     if (p.relu) v = fmaxf(v, 0.f);
                     const int64_t orow = p.rowmap ? p.rowmap[m] : m;
-                    C[orow * p.ldc + n] = v;
+                    if (splitk > 1) atomicAdd(&C[orow * p.ldc + n], v);
+                    else C[orow * p.ldc + n] = v;
+                    if (C2) C2[orow * p.ldc + n] = v * sc2;
                 }
             }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
 int launch_cfg(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     constexpr int smem = 2 * stage_f4<BM, BN>() * 16;
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, MODE>;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AMODE, BMODE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -220,24 +378,40 @@ int launch_cfg(const GemmArgs& a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid(tiles_m * tiles_n, 1, a.groups > 0 ? a.groups : 1);
+    const int splitk = a.splitk > 1 ? a.splitk : 1;
+    dim3 grid(tiles_m * tiles_n, 1, (a.groups > 0 ? a.groups : 1) * splitk);
     if (prof_enabled()) {
         char nm[64];
-        snprintf(nm, sizeof(nm), "gemm_f32_kernel<%d,%d,%d,%d,%d>", BM, BN, WM, WN, MODE);
+        snprintf(nm, sizeof(nm), "gemm_f32_kernel<%d,%d,%d,%d,%d,%d>", BM, BN, WM, WN, AMODE, BMODE);
         const double g = a.groups;
+        double abytes;
+        if (AMODE == A_CONV) abytes = (double)(a.M / (a.Ho * a.Wo)) * a.H * a.W * a.Cin;
+        else if (AMODE == A_DGRAD) abytes = (double)(a.M / (a.H * a.W)) * a.Ho * a.Wo * (a.K / (a.KH * a.KW));
+        else abytes = (double)a.M * a.K;
+        const double bbytes = (BMODE == B_WGRAD) ? (double)(a.K / (a.Ho * a.Wo)) * a.H * a.W * a.Cin : (double)a.N * a.K;
         // algorithmic work: 2*M*N*K flops; operands read once + result written once
-        prof_begin(nm, 2.0 * a.M * a.N * a.K * g, 4.0 * g * ((double)a.M * a.N + (double)a.N * a.K +
-                   (MODE == 0 ? (double)a.M * a.K : (double)(a.M / (a.Ho * a.Wo)) * a.H * a.W * a.Cin)), st);
+        prof_begin(nm, 2.0 * a.M * a.N * a.K * g, 4.0 * g * ((double)a.M * a.N + abytes + bbytes), st);
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a, tiles_m, tiles_n);
     prof_end(st);
     return (int)hipGetLastError();
 }
 
-double tile_eff(int M, int N, int groups, int BM, int BN, double factor) {
-    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * groups;
+double tile_eff(int M, int N, int nz, int BM, int BN, double factor) {
+    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * nz;
     const long rounds = (tiles + 255) / 256;
-    return factor * ((double)M * N * groups) / ((double)rounds * 256 * BM * BN);
+    return factor * ((double)M * N * nz) / ((double)rounds * 256 * BM * BN);
+}
+
+template <int AMODE, int BMODE>
+int launch_modes(const GemmArgs& a, hipStream_t st) {
+    const int nz = (a.groups > 0 ? a.groups : 1) * (a.splitk > 1 ? a.splitk : 1);
+    const double eL = tile_eff(a.M, a.N, nz, 128, 128, 1.00);
+    const double eM = tile_eff(a.M, a.N, nz, 128, 64, 0.95);
+    const double eS = tile_eff(a.M, a.N, nz, 64, 64, 0.88);
+    if (eL >= eM && eL >= eS) return launch_cfg<128, 128, 64, 64, AMODE, BMODE>(a, st);
+    if (eM >= eS) return launch_cfg<128, 64, 64, 32, AMODE, BMODE>(a, st);
+    return launch_cfg<64, 64, 32, 32, AMODE, BMODE>(a, st);
 }
 
 }  // namespace
@@ -247,31 +421,56 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t st, std::string* err) {
     if (a.groups <= 0) a.groups = 1;
     if (a.M <= 0 || a.N <= 0) return 0;
     auto fail = [&](const char* m) { if (err) *err = std::string("gemm: ") + m; return -2; };
-    if (a.K <= 0 || (a.K & 3)) return fail("K must be a positive multiple of 4");
-    if (a.ldb & 3) return fail("ldb must be a multiple of 4");
+    if (a.K <= 0) return fail("K must be positive");
     if (((uintptr_t)a.A & 15) || ((uintptr_t)a.Bw & 15)) return fail("A/B must be 16-byte aligned");
-    if (a.mode == 0) {
+    if (a.splitk > 1 && (a.bias || a.res || a.mask || a.relu || a.C2 || a.scale)) return fail("split-K supports a plain accumulate only");
+    if (a.C2 && !a.scale2) return fail("C2 needs scale2");
+    int amode, bmode = a.tb;
+    if (a.ta) {
+        if (a.mode != 0) return fail("ta requires mode 0");
         if (a.lda & 3) return fail("lda must be a multiple of 4");
-        if (a.A_add && ((a.ld_add & 3) || a.add_mod <= 0 || ((uintptr_t)a.A_add & 15))) return fail("bad addend");
+        if (a.A_add || a.a_rowmap) return fail("addend / row gather not supported with ta");
+        amode = A_T;
     } else {
-        if (a.Cin & 3) return fail("Cin must be a multiple of 4");
-        if (a.K != a.KH * a.KW * a.Cin) return fail("K != KH*KW*Cin");
-        if (a.A_add) return fail("addend not supported in conv mode");
-        if (a.M % (a.Ho * a.Wo)) return fail("M must be images*Ho*Wo");
+        if (a.mode == 0) {
+            if (a.lda & 3) return fail("lda must be a multiple of 4");
+            // a ragged K is fine when the rows are padded to a multiple of 4 with finite values (the B side is
+            // zero-filled beyond K, so the pad never contributes)
+            if ((a.K & 3) && a.lda < ((a.K + 3) & ~3)) return fail("K % 4 != 0 needs rows padded to a multiple of 4");
+            if (a.A_add && ((a.ld_add & 3) || a.add_mod <= 0 || ((uintptr_t)a.A_add & 15))) return fail("bad addend");
+            amode = A_N;
+        } else if (a.mode == 1) {
+            if (a.K & 3) return fail("K must be a multiple of 4");
+            if (a.Cin & 3) return fail("Cin must be a multiple of 4");
+            if (a.K != a.KH * a.KW * a.Cin) return fail("K != KH*KW*Cin");
+            if (a.A_add || a.a_rowmap) return fail("addend not supported in conv mode");
+            if (a.M % (a.Ho * a.Wo)) return fail("M must be images*Ho*Wo");
+            amode = A_CONV;
+        } else if (a.mode == 2) {
+            if (a.K % (a.KH * a.KW) || ((a.K / (a.KH * a.KW)) & 3)) return fail("dgrad: K must be KH*KW*Cout, Cout % 4 == 0");
+            if (a.M % (a.H * a.W)) return fail("dgrad: M must be images*H*W");
+            amode = A_DGRAD;
+        } else return fail("bad mode");
     }
-    const double eL = tile_eff(a.M, a.N, a.groups, 128, 128, 1.00);
-    const double eM = tile_eff(a.M, a.N, a.groups, 128, 64, 0.95);
-    const double eS = tile_eff(a.M, a.N, a.groups, 64, 64, 0.88);
+    if (bmode == 0) {
+        if ((a.ldb & 3) || (a.K & 3)) return fail("ldb and K must be multiples of 4 for a contraction-contiguous B");
+    } else if (bmode == 1) {
+        if (a.ldb & 3) return fail("ldb must be a multiple of 4");
+        if (a.B_add && ((a.ld_badd & 3) || a.badd_mod <= 0)) return fail("bad B addend");
+    } else if (bmode == 2) {
+        if ((a.Cin & 3) || a.N != a.KH * a.KW * a.Cin) return fail("wgrad: N must be KH*KW*Cin, Cin % 4 == 0");
+        if (a.K % (a.Ho * a.Wo)) return fail("wgrad: K must be images*Ho*Wo");
+        if (!a.ta) return fail("wgrad: A (dY) must be given in [m][n] storage (ta=1)");
+    } else return fail("bad tb");
     int rc;
-    if (a.mode == 0) {
-        if (eL >= eM && eL >= eS) rc = launch_cfg<128, 128, 64, 64, 0>(a, st);
-        else if (eM >= eS) rc = launch_cfg<128, 64, 64, 32, 0>(a, st);
-        else rc = launch_cfg<64, 64, 32, 32, 0>(a, st);
-    } else {
-        if (eL >= eM && eL >= eS) rc = launch_cfg<128, 128, 64, 64, 1>(a, st);
-        else if (eM >= eS) rc = launch_cfg<128, 64, 64, 32, 1>(a, st);
-        else rc = launch_cfg<64, 64, 32, 32, 1>(a, st);
-    }
+    if (amode == A_N && bmode == B_N) rc = launch_modes<A_N, B_N>(a, st);
+    else if (amode == A_CONV && bmode == B_N) rc = launch_modes<A_CONV, B_N>(a, st);
+    else if (amode == A_DGRAD && bmode == B_N) rc = launch_modes<A_DGRAD, B_N>(a, st);
+    else if (amode == A_N && bmode == B_T) rc = launch_modes<A_N, B_T>(a, st);
+    else if (amode == A_T && bmode == B_T) rc = launch_modes<A_T, B_T>(a, st);
+    else if (amode == A_T && bmode == B_WGRAD) rc = launch_modes<A_T, B_WGRAD>(a, st);
+    else if (amode == A_T && bmode == B_N) rc = launch_modes<A_T, B_N>(a, st);
+    else return fail("operand form combination not instantiated");
     if (rc != 0 && err) *err = std::string("gemm launch: ") + hipGetErrorString((hipError_t)rc);
     return rc == 0 ? 0 : -3;
 }

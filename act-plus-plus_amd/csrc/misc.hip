@@ -116,7 +116,117 @@ __global__ void build_rowmap_kernel(int* __restrict__ map, int B, int C, int fh,
     map[m] = b * N + 2 + h * (fw * C) + cam * fw + w;
 }
 
+// image (u8 NHWC [B][C][H][W][3] or f32 NCHW [B][C][3][H][W]) -> normalised f32 camera-major NHWC4 [C][B][H][W][4]
+// (4th channel zero) so that the conv1 weight gradient can use the generic implicit-GEMM gather (Cin % 4 == 0)
+__global__ void normalize_pad_kernel(const void* __restrict__ image, int fmt, const float* __restrict__ lut,
+                                     float* __restrict__ out, int B, int C, int H, int W, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // over [C][B][H][W]
+    if (idx >= total) return;
+    const int w = (int)(idx % W);
+    int64_t r = idx / W;
+    const int h = (int)(r % H); r /= H;
+    const int b = (int)(r % B);
+    const int cam = (int)(r / B);
+    const int64_t img = (int64_t)b * C + cam;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (fmt == 0) {
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(image) + (img * H * W + (int64_t)h * W + w) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = lut[c * 256 + src[c]];
+    } else {
+        const float* src = reinterpret_cast<const float*>(image) + img * 3 * H * W + (int64_t)h * W + w;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (src[(int64_t)c * H * W] - mean[c]) / stdv[c];
+    }
+    reinterpret_cast<f32x4*>(out)[idx] = v;
+}
+
+// dst[m][:] = src[map[m]][:]
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ map, float* __restrict__ dst,
+                                   int D4, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int64_t m = idx / D4;
+    const int d = (int)(idx - m * D4);
+    reinterpret_cast<f32x4*>(dst)[idx] = reinterpret_cast<const f32x4*>(src)[(int64_t)map[m] * D4 + d];
+}
+
+// dW[n][k] += sum_m dy[m*lddy + n] * x[m*ldx + k]   (tiny K such as the 14-wide qpos projections)
+__global__ void small_linear_wgrad_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                                          int64_t ldx, float* __restrict__ dW, int M, int N, int K) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * K) return;
+    const int n = (int)(idx / K), k = (int)(idx - (int64_t)n * K);
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m) acc = fmaf(dy[(int64_t)m * lddy + n], x[(int64_t)m * ldx + k], acc);
+    dW[idx] += acc;
+}
+
+// CVAE token rows: map[m = b*Q + t] = b*(Q+2) + 2 + t ; key padding mask [B][Q+2] = [0, 0, is_pad]
+__global__ void cvae_maps_kernel(int* __restrict__ map, uint8_t* __restrict__ kpm, const uint8_t* __restrict__ is_pad, int B,
+                                 int Q) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < B * Q) map[idx] = (idx / Q) * (Q + 2) + 2 + idx % Q;
+    if (idx < B * (Q + 2)) {
+        const int b = idx / (Q + 2), j = idx % (Q + 2);
+        kpm[idx] = j < 2 ? 0 : is_pad[b * Q + j - 2];
+    }
+}
+
+__global__ void bcast_add_rows_kernel(float* __restrict__ dst, const float* __restrict__ vec, int D, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) dst[i] += vec[i % D];
+}
+
+__global__ void axpy_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 }  // namespace
+
+int launch_normalize_pad(const void* image, int fmt, const float* lut, float* out, int B, int C, int H, int W,
+                         hipStream_t st) {
+    const int64_t total = (int64_t)C * B * H * W;
+    hipLaunchKernelGGL(normalize_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, image, fmt, lut, out, B, C,
+                       H, W, total);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_gather_rows(const float* src, const int* map, float* dst, int M, int D, hipStream_t st) {
+    const int64_t total = (int64_t)M * (D / 4);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, map, dst, D / 4, total);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_small_linear_wgrad(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dW, int M, int N, int K,
+                              hipStream_t st) {
+    const int64_t total = (int64_t)N * K;
+    hipLaunchKernelGGL(small_linear_wgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, lddy, x, ldx, dW, M,
+                       N, K);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_cvae_maps(int* map, uint8_t* kpm, const uint8_t* is_pad, int B, int Q, hipStream_t st) {
+    const int total = B * (Q + 2);
+    hipLaunchKernelGGL(cvae_maps_kernel, dim3((total + 255) / 256), dim3(256), 0, st, map, kpm, is_pad, B, Q);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_bcast_add_rows(float* dst, const float* vec, int R, int D, hipStream_t st) {
+    const int64_t total = (int64_t)R * D;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(bcast_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dst, vec, D, total);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_axpy(float* dst, const float* src, int64_t n, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(axpy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, src, n);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 
 int launch_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale, float* bias, int n,
                    hipStream_t st) {

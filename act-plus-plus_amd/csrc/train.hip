@@ -1,0 +1,715 @@
+// Training step of the ACT policy on MI355X: forward with saved activations, L1+KL loss, full backward,
+// fused AdamW.  Reference semantics: ACTPolicy.__call__ training branch (policy.py:288-320), DETRVAE.forward with
+// actions (detr_vae.py:107-161, 163-254), torch autograd, torch.optim.AdamW with the two parameter groups of
+// detr/main.py:102-110.  Every contraction (forward, data gradient, weight gradient, attention products) runs on
+// the fp32 MFMA kernel family of gemm.hip; the remaining pieces are the kernels of bwd.hip / misc.hip.
+//
+// Quirks preserved: only decoder layer 0 reaches the loss; layers 1.. get exactly-zero gradients and
+// therefore only AdamW's decoupled weight decay; is_pad_head gets no gradient at all (skipped by the optimizer, like
+// a parameter whose .grad is None); the decoder layer-0 self-attention on tgt = 0 reduces to out_proj(b_v) + b_o, so
+// its q/k projections and the v weight receive exactly-zero gradients while b_v, out_proj and norm1 do not.
+#include "engine.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+#define CHK(expr)                                                                               \
+    do {                                                                                        \
+        int _rc = (expr);                                                                       \
+        if (_rc != 0) {                                                                         \
+            if (ctx->err.empty()) ctx->err = std::string("failed: ") + #expr;                   \
+            return _rc < -5 ? ACTMI_E_LAUNCH : _rc;                                             \
+        }                                                                                       \
+    } while (0)
+
+#define HIPCHK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+            return ACTMI_E_LAUNCH;                                                              \
+        }                                                                                       \
+    } while (0)
+
+int talloc(actmi_ctx* ctx, float** p, int64_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, (size_t)(n > 0 ? n : 1) * sizeof(float)) != hipSuccess) {
+        ctx->err = "hipMalloc failed (training buffers)";
+        return ACTMI_E_NOMEM;
+    }
+    ctx->allocs.push_back(q);
+    *p = reinterpret_cast<float*>(q);
+    return 0;
+}
+
+GemmArgs G0() {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.groups = 1;
+    return a;
+}
+
+int pick_splitk(int M, int N, int groups, int K) {
+    const long tiles = (long)((M + 127) / 128) * ((N + 63) / 64) * groups;
+    long s = 1024 / (tiles > 0 ? tiles : 1);
+    const long nk = (K + 31) / 32;
+    if (s > nk / 4) s = nk / 4;          // keep >= 4 k-tiles per split
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return (int)s;
+}
+
+// y[M][N] = x[M][K] W[N][K]^T + b (+res) (relu)
+int lin_fwd(actmi_ctx* ctx, const float* x, int64_t ldx, int M, int K, const float* W, int N, const float* b, float* y,
+            int64_t ldy, const float* res, int relu, hipStream_t st) {
+    GemmArgs a = G0();
+    a.A = x; a.lda = ldx; a.M = M; a.K = K; a.N = N; a.Bw = W; a.ldb = K; a.bias = b; a.C = y; a.ldc = ldy;
+    a.res = res; a.ldres = ldy; a.relu = relu;
+    return launch_gemm(a, st, &ctx->err);
+}
+
+// dx[M][K] = dy[M][N] W[N][K] (+res) (masked by mask>0)
+int lin_dgrad(actmi_ctx* ctx, const float* dy, int64_t lddy, int M, int N, const float* W, int K, float* dx, int64_t lddx,
+              const float* res, const float* mask, hipStream_t st) {
+    GemmArgs a = G0();
+    a.A = dy; a.lda = lddy; a.M = M; a.K = N; a.N = K; a.Bw = W; a.ldb = K; a.tb = 1; a.C = dx; a.ldc = lddx;
+    a.res = res; a.ldres = lddx; a.mask = mask; a.ldmask = lddx;
+    return launch_gemm(a, st, &ctx->err);
+}
+
+// dW[N][K] += dy[M][N]^T x'[M][K],  x' = x + x_add[m % add_mod];  db[N] += colsum(dy)
+int lin_wgrad(actmi_ctx* ctx, const float* dy, int64_t lddy, int M, int N, const float* x, int64_t ldx, int K,
+              const float* x_add, int add_mod, float* dW, float* db, hipStream_t st) {
+    if (dW) {
+        GemmArgs a = G0();
+        a.A = dy; a.lda = lddy; a.ta = 1; a.M = N; a.K = M; a.Bw = x; a.ldb = ldx; a.tb = 1; a.N = K;
+        a.B_add = x_add; a.ld_badd = K; a.badd_mod = add_mod > 0 ? add_mod : 1;
+        a.C = dW; a.ldc = K;
+        a.splitk = pick_splitk(N, K, 1, M);
+        if (a.splitk <= 1) { a.splitk = 0; a.res = dW; a.ldres = K; }
+        CHK(launch_gemm(a, st, &ctx->err));
+    }
+    if (db) CHK(launch_colsum(dy, lddy, db, M, N, st));
+    return 0;
+}
+
+// ---- attention backward through materialised probabilities (batched MFMA products) -------------------------------
+struct AttnBwd {
+    const float *Q, *K, *V, *O, *dO, *lse;
+    int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs;     // forward operand strides (q_bs = 0: shared queries)
+    float *dQ, *dK, *dV;
+    int64_t dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+    const uint8_t* kpm; int64_t kpm_bs;
+    int B, H, Nq, Nk, HD;
+};
+
+int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
+    TrainState& T = *ctx->train;
+    const int G = t.B * t.H, D = t.H * t.HD;
+    const int ldp = (t.Nk + 3) & ~3;
+    const float scale = 1.0f / sqrtf((float)t.HD);
+    float* P = T.Pbuf;
+    float* dP = T.dPbuf;
+    const int64_t pg = (int64_t)t.Nq * ldp;
+    // S = scale * Q K^T
+    GemmArgs s = G0();
+    s.A = t.Q; s.lda = t.q_rs; s.M = t.Nq; s.K = t.HD; s.Bw = t.K; s.ldb = t.k_rs; s.N = t.Nk; s.C = P; s.ldc = ldp;
+    s.alpha = scale; s.groups = G; s.groups_inner = t.H;
+    s.gA = t.q_bs; s.gA2 = t.HD; s.gB = t.k_bs; s.gB2 = t.HD; s.gC = pg * t.H; s.gC2 = pg;
+    CHK(launch_gemm(s, st, &ctx->err));
+    CHK(launch_attn_probs(P, t.lse, t.kpm, t.kpm_bs, G, t.H, t.Nq, t.Nk, ldp, st));
+    // dP = dO V^T
+    GemmArgs d = G0();
+    d.A = t.dO; d.lda = D; d.M = t.Nq; d.K = t.HD; d.Bw = t.V; d.ldb = t.v_rs; d.N = t.Nk; d.C = dP; d.ldc = ldp;
+    d.groups = G; d.groups_inner = t.H;
+    d.gA = (int64_t)t.Nq * D; d.gA2 = t.HD; d.gB = t.v_bs; d.gB2 = t.HD; d.gC = pg * t.H; d.gC2 = pg;
+    CHK(launch_gemm(d, st, &ctx->err));
+    CHK(launch_attn_delta(t.dO, t.O, T.delta, t.B, t.H, t.Nq, t.HD, st));
+    // dV[key][d] = sum_q P[q][key] dO[q][d]
+    GemmArgs v = G0();
+    v.A = P; v.lda = ldp; v.ta = 1; v.M = t.Nk; v.K = t.Nq; v.Bw = t.dO; v.ldb = D; v.tb = 1; v.N = t.HD;
+    v.C = t.dV; v.ldc = t.dv_rs; v.groups = G; v.groups_inner = t.H;
+    v.gA = pg * t.H; v.gA2 = pg; v.gB = (int64_t)t.Nq * D; v.gB2 = t.HD; v.gC = t.dv_bs; v.gC2 = t.HD;
+    CHK(launch_gemm(v, st, &ctx->err));
+    // dS = P * (dP - delta) * scale   (in place of dP)
+    CHK(launch_attn_ds(P, dP, T.delta, scale, G, t.Nq, t.Nk, ldp, st));
+    // dQ[q][d] = sum_key dS[q][key] K[key][d]
+    GemmArgs q = G0();
+    q.A = dP; q.lda = ldp; q.M = t.Nq; q.K = t.Nk; q.Bw = t.K; q.ldb = t.k_rs; q.tb = 1; q.N = t.HD;
+    q.C = t.dQ; q.ldc = t.dq_rs; q.groups = G; q.groups_inner = t.H;
+    q.gA = pg * t.H; q.gA2 = pg; q.gB = t.k_bs; q.gB2 = t.HD; q.gC = t.dq_bs; q.gC2 = t.HD;
+    CHK(launch_gemm(q, st, &ctx->err));
+    // dK[key][d] = sum_q dS[q][key] Q[q][d]
+    GemmArgs k = G0();
+    k.A = dP; k.lda = ldp; k.ta = 1; k.M = t.Nk; k.K = t.Nq; k.Bw = t.Q; k.ldb = t.q_rs; k.tb = 1; k.N = t.HD;
+    k.C = t.dK; k.ldc = t.dk_rs; k.groups = G; k.groups_inner = t.H;
+    k.gA = pg * t.H; k.gA2 = pg; k.gB = t.q_bs; k.gB2 = t.HD; k.gC = t.dk_bs; k.gC2 = t.HD;
+    CHK(launch_gemm(k, st, &ctx->err));
+    return 0;
+}
+
+// ---- one post-norm encoder layer, forward with saved activations (transformer.py:211-224) ------------------------
+int enc_fwd(actmi_ctx* ctx, const EncW& w, EncSave& s, float* out, const float* pos, int B, int n, const uint8_t* kpm,
+            hipStream_t st) {
+    const actmi_config& g = ctx->cfg;
+    const int D = g.hidden_dim, F = g.dim_feedforward, M = B * n, hd = D / g.nheads;
+    GemmArgs qkv = G0();
+    qkv.A = s.x_in; qkv.lda = D; qkv.M = M; qkv.K = D; qkv.Bw = w.attn.in_w; qkv.ldb = D; qkv.N = 3 * D;
+    qkv.bias = w.attn.in_b; qkv.C = s.QKV; qkv.ldc = 3 * D;
+    qkv.A_add = pos; qkv.ld_add = D; qkv.add_mod = n; qkv.add_ncols = 2 * D;
+    CHK(launch_gemm(qkv, st, &ctx->err));
+    AttnArgs at;
+    memset(&at, 0, sizeof(at));
+    at.Q = s.QKV; at.q_bs = (int64_t)n * 3 * D; at.q_rs = 3 * D;
+    at.K = s.QKV + D; at.k_bs = at.q_bs; at.k_rs = 3 * D;
+    at.V = s.QKV + 2 * D; at.v_bs = at.q_bs; at.v_rs = 3 * D;
+    at.O = s.ATT; at.o_bs = (int64_t)n * D; at.o_rs = D;
+    at.kpm = kpm; at.kpm_bs = n; at.lse = s.lse;
+    at.B = B; at.H = g.nheads; at.Nq = n; at.Nk = n; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
+    CHK(launch_attention(at, st, &ctx->err));
+    CHK(lin_fwd(ctx, s.ATT, D, M, D, w.attn.out_w, D, w.attn.out_b, s.Y1, D, s.x_in, 0, st));
+    CHK(launch_layernorm(s.Y1, nullptr, 0, w.n1w, w.n1b, nullptr, nullptr, s.X1, M, D, 1e-5f, st, &ctx->err));
+    CHK(lin_fwd(ctx, s.X1, D, M, D, w.l1w, F, w.l1b, s.Hb, F, nullptr, 1, st));
+    CHK(lin_fwd(ctx, s.Hb, F, M, F, w.l2w, D, w.l2b, s.Y2, D, s.X1, 0, st));
+    CHK(launch_layernorm(s.Y2, nullptr, 0, w.n2w, w.n2b, nullptr, nullptr, out, M, D, 1e-5f, st, &ctx->err));
+    return 0;
+}
+
+// backward of the same layer: dOut -> dIn (dIn may alias T.gB); grads accumulate into the gradient arena
+int enc_bwd(actmi_ctx* ctx, const EncW& w, const EncSave& s, const float* dOut, float* dIn, const float* pos, int B, int n,
+            const uint8_t* kpm, float* dpos2 /* [2][D] additional_pos_embed grad or null */, hipStream_t st) {
+    TrainState& T = *ctx->train;
+    const actmi_config& g = ctx->cfg;
+    const int D = g.hidden_dim, F = g.dim_feedforward, M = B * n, hd = D / g.nheads;
+    auto Gp = [&](const float* p) { return T.gbase + (p - ctx->pbase); };
+    float* gA = T.gA; float* gC = T.gC; float* gH = T.gH; float* gQKV = T.gQKV;
+    float* gB = T.gB;
+    // norm2
+    CHK(launch_ln_bwd(s.Y2, w.n2w, dOut, nullptr, gA, Gp(w.n2w), Gp(w.n2b), M, D, 1e-5f, st));             // gA = dY2
+    // linear2 / relu / linear1
+    CHK(lin_dgrad(ctx, gA, D, M, D, w.l2w, F, gH, F, nullptr, s.Hb, st));                                    // gH = dHpre
+    CHK(lin_wgrad(ctx, gA, D, M, D, s.Hb, F, F, nullptr, 0, Gp(w.l2w), Gp(w.l2b), st));
+    CHK(lin_dgrad(ctx, gH, F, M, F, w.l1w, D, gC, D, gA, nullptr, st));                                      // gC = dX1
+    CHK(lin_wgrad(ctx, gH, F, M, F, s.X1, D, D, nullptr, 0, Gp(w.l1w), Gp(w.l1b), st));
+    // norm1
+    CHK(launch_ln_bwd(s.Y1, w.n1w, gC, nullptr, gA, Gp(w.n1w), Gp(w.n1b), M, D, 1e-5f, st));               // gA = dY1
+    // out_proj
+    CHK(lin_dgrad(ctx, gA, D, M, D, w.attn.out_w, D, gC, D, nullptr, nullptr, st));                         // gC = dATT
+    CHK(lin_wgrad(ctx, gA, D, M, D, s.ATT, D, D, nullptr, 0, Gp(w.attn.out_w), Gp(w.attn.out_b), st));
+    // attention
+    AttnBwd t;
+    memset(&t, 0, sizeof(t));
+    const int64_t bs = (int64_t)n * 3 * D;
+    t.Q = s.QKV; t.K = s.QKV + D; t.V = s.QKV + 2 * D; t.O = s.ATT; t.dO = gC; t.lse = s.lse;
+    t.q_bs = t.k_bs = t.v_bs = bs; t.q_rs = t.k_rs = t.v_rs = 3 * D;
+    t.dQ = gQKV; t.dK = gQKV + D; t.dV = gQKV + 2 * D;
+    t.dq_bs = t.dk_bs = t.dv_bs = bs; t.dq_rs = t.dk_rs = t.dv_rs = 3 * D;
+    t.kpm = kpm; t.kpm_bs = n; t.B = B; t.H = g.nheads; t.Nq = n; t.Nk = n; t.HD = hd;
+    CHK(attn_bwd(ctx, t, st));
+    // in_proj: dIn = dQKV W_in + dY1 ; dW rows [0,2D) see x+pos, rows [2D,3D) see x
+    CHK(lin_dgrad(ctx, gQKV, 3 * D, M, 3 * D, w.attn.in_w, D, dIn == gB ? gB : dIn, D, gA, nullptr, st));
+    CHK(lin_wgrad(ctx, gQKV, 3 * D, M, 2 * D, s.x_in, D, D, pos, n, Gp(w.attn.in_w), nullptr, st));
+    CHK(lin_wgrad(ctx, gQKV + 2 * D, 3 * D, M, D, s.x_in, D, D, nullptr, 0, Gp(w.attn.in_w) + (int64_t)2 * D * D, nullptr, st));
+    CHK(launch_colsum(gQKV, 3 * D, Gp(w.attn.in_b), M, 3 * D, st));
+    if (dpos2) {
+        // additional_pos_embed rows: d(x+pos)[b][j] = dQK[b][j] W_in[0:2D], summed over the batch, j in {0,1}
+        GemmArgs a = G0();
+        a.A = gQKV; a.lda = 3 * D; a.a_rowmap = T.pos_rows; a.M = 2 * B; a.K = 2 * D; a.Bw = w.attn.in_w; a.ldb = D; a.tb = 1;
+        a.N = D; a.C = T.tmp2BD; a.ldc = D;
+        CHK(launch_gemm(a, st, &ctx->err));
+        CHK(launch_sum_batch(T.tmp2BD, 2 * D, D, dpos2, B, 2, D, 1, st));
+    }
+    return 0;
+}
+
+// ---- convolution backward pieces --------------------------------------------------------------------------------------
+int conv_wgrad(actmi_ctx* ctx, const ConvLayer& cl, int li, const float* dys, const float* x, int B, hipStream_t st) {
+    TrainState& T = *ctx->train;
+    const int C = ctx->cfg.num_cams;
+    GemmArgs a = G0();
+    a.A = dys; a.lda = cl.cout; a.ta = 1; a.M = cl.cout; a.K = B * cl.Ho * cl.Wo;
+    a.Bw = x; a.tb = 2; a.N = cl.K; a.H = cl.H; a.W = cl.W; a.Cin = cl.cin; a.KH = a.KW = cl.k; a.stride = cl.stride;
+    a.pad = cl.pad; a.Ho = cl.Ho; a.Wo = cl.Wo; a.img_stride = (int64_t)cl.H * cl.W * cl.cin;
+    a.C = T.conv_gw[li]; a.ldc = cl.K; a.groups = C;
+    a.gA = (int64_t)B * cl.Ho * cl.Wo * cl.cout; a.gB = (int64_t)B * cl.H * cl.W * cl.cin; a.gC = (int64_t)cl.cout * cl.K;
+    a.splitk = pick_splitk(cl.cout, cl.K, C, a.K);
+    if (a.splitk <= 1) { a.splitk = 0; a.res = a.C; a.ldres = cl.K; a.gRes = a.gC; }
+    return launch_gemm(a, st, &ctx->err);
+}
+
+// dx[C][B][H][W][cin] = dgrad(dys) (+res) , then masked by (mask > 0) and multiplied by scale[cin] (previous BN)
+int conv_dgrad(actmi_ctx* ctx, const ConvLayer& cl, int li, const float* dys, float* dx, const float* res, const float* mask,
+               const float* scale, int B, hipStream_t st) {
+    TrainState& T = *ctx->train;
+    const int C = ctx->cfg.num_cams;
+    GemmArgs a = G0();
+    a.mode = 2; a.A = dys; a.H = cl.H; a.W = cl.W; a.Cin = cl.cin; a.KH = a.KW = cl.k; a.stride = cl.stride; a.pad = cl.pad;
+    a.Ho = cl.Ho; a.Wo = cl.Wo; a.img_stride = (int64_t)cl.Ho * cl.Wo * cl.cout;
+    a.M = B * cl.H * cl.W; a.N = cl.cin; a.K = cl.k * cl.k * cl.cout;
+    a.Bw = T.conv_wd[li]; a.ldb = a.K; a.C = dx; a.ldc = cl.cin; a.groups = C;
+    a.gA = (int64_t)B * cl.Ho * cl.Wo * cl.cout; a.gB = (int64_t)cl.cin * a.K; a.gC = (int64_t)a.M * cl.cin;
+    a.res = res; a.ldres = cl.cin; a.gRes = a.gC; a.mask = mask; a.ldmask = cl.cin; a.gMask = a.gC;
+    a.scale = scale; a.gSB = cl.cin;
+    return launch_gemm(a, st, &ctx->err);
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------------------------------
+// allocation
+// ----------------------------------------------------------------------------------------------------------------------
+
+int train_create(actmi_ctx* ctx) {
+    const actmi_config& g = ctx->cfg;
+    ctx->train = new TrainState();
+    TrainState& T = *ctx->train;
+    const int B = g.max_batch, C = g.num_cams, D = g.hidden_dim, F = g.dim_feedforward, Q = g.num_queries, N = ctx->N,
+              w0 = g.base_width, H = g.nheads, L = g.latent_dim, A = g.action_dim;
+    int rc;
+#define TA(ptr, n) if ((rc = talloc(ctx, &(ptr), (n)))) return rc
+    TA(T.gbase, ctx->ptotal); TA(T.mbase, ctx->ptotal); TA(T.vbase, ctx->ptotal);
+    if (hipMemset(T.gbase, 0, ctx->ptotal * 4) != hipSuccess || hipMemset(T.mbase, 0, ctx->ptotal * 4) != hipSuccess ||
+        hipMemset(T.vbase, 0, ctx->ptotal * 4) != hipSuccess) { ctx->err = "hipMemset failed"; return ACTMI_E_LAUNCH; }
+    {
+        // optimizer group per 64-float slot: 0 skip (buffers; is_pad_head never gets a grad), 1 lr, 2 lr_backbone
+        std::vector<uint8_t> grp((size_t)(ctx->ptotal / 64), 0);
+        for (const Param& p : ctx->params) {
+            uint8_t gcode = 0;
+            if (!p.is_buffer && p.key.rfind("is_pad_head", 0) != 0) gcode = p.key.find("backbone") != std::string::npos ? 2 : 1;
+            for (int64_t c = p.off / 64; c < (p.off + ((p.numel + 63) & ~int64_t(63))) / 64; ++c) grp[(size_t)c] = gcode;
+        }
+        float* gp = nullptr;
+        TA(gp, (int64_t)(grp.size() + 3) / 4);
+        T.group = reinterpret_cast<uint8_t*>(gp);
+        if (hipMemcpy(T.group, grp.data(), grp.size(), hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "hipMemcpy failed"; return ACTMI_E_LAUNCH; }
+    }
+    // backbone saves
+    const int64_t n2 = (int64_t)C * B * ctx->H2 * ctx->W2 * w0;
+    const int64_t n1 = (int64_t)C * B * ctx->H1 * ctx->W1 * w0;
+    TA(T.xn4, (int64_t)C * B * g.image_h * g.image_w * 4);
+    TA(T.pool, n2);
+    TA(T.g_act1, n1);
+    for (int i = 0; i < 4; ++i) TA(T.gbuf[i], n2);
+    {
+        size_t ci = 0;
+        for (int li = 1; li <= 4; ++li)
+            for (int bi = 0; bi < 2; ++bi) {
+                const ConvLayer& k1 = ctx->convs[ci];
+                BlockSave bs;
+                bs.c1 = (int)ci; bs.c2 = (int)ci + 1; bs.ds = (bi == 0 && li > 1) ? (int)ci + 2 : -1;
+                ci += (bs.ds >= 0) ? 3 : 2;
+                const int64_t nout = (int64_t)C * B * k1.Ho * k1.Wo * k1.cout;
+                TA(bs.y1, nout); TA(bs.out, nout);
+                T.blocks.push_back(bs);
+            }
+    }
+    for (auto& cl : ctx->convs) {
+        float *gw, *wd;
+        TA(gw, (int64_t)C * cl.cout * cl.K); TA(wd, (int64_t)C * cl.cin * cl.k * cl.k * cl.cout);
+        T.conv_gw.push_back(gw); T.conv_wd.push_back(wd);
+    }
+    TA(T.conv1_gw, (int64_t)C * w0 * 196);
+    // transformer saves
+    auto alloc_enc = [&](std::vector<EncSave>& v, int n, float* first_in) -> int {
+        const int64_t M = (int64_t)B * n;
+        for (int l = 0; l < g.enc_layers; ++l) {
+            EncSave s;
+            if (l == 0 && first_in) s.x_in = first_in; else TA(s.x_in, M * D);
+            TA(s.QKV, M * 3 * D); TA(s.ATT, M * D); TA(s.Y1, M * D); TA(s.X1, M * D); TA(s.Hb, M * F); TA(s.Y2, M * D);
+            TA(s.lse, (int64_t)B * H * n);
+            v.push_back(s);
+        }
+        return 0;
+    };
+    if ((rc = alloc_enc(T.en, N, ctx->X))) return rc;
+    TA(T.mem, (int64_t)B * N * D);
+    if (g.has_cvae_encoder) {
+        TA(T.Xc, (int64_t)B * (Q + 2) * D);
+        if ((rc = alloc_enc(T.cv, Q + 2, T.Xc))) return rc;
+        TA(T.cv_out, (int64_t)B * (Q + 2) * D);
+        float* t1; TA(t1, (int64_t)B * Q); T.cmap = reinterpret_cast<int*>(t1);
+        float* t2; TA(t2, ((int64_t)B * (Q + 2) + 3) / 4 + 1); T.ckpm = reinterpret_cast<uint8_t*>(t2);
+        TA(T.latent_info, (int64_t)B * 2 * L); TA(T.z, (int64_t)B * L); TA(T.eps, (int64_t)B * L);
+        TA(T.d_latent_info, (int64_t)B * 2 * L); TA(T.dz, (int64_t)B * L);
+    }
+    // decoder layer 0 saves
+    const int64_t BQ = (int64_t)B * Q;
+    TA(T.sa_tmp, D); TA(T.t1, D); TA(T.qin, (int64_t)Q * D); TA(T.dq, (int64_t)Q * D);
+    TA(T.KV, (int64_t)B * N * 2 * D); TA(T.lse_c, (int64_t)B * H * Q); TA(T.Oc, BQ * D); TA(T.Y2pre, BQ * D);
+    TA(T.T2, BQ * D); TA(T.Hd, BQ * F); TA(T.Y3pre, BQ * D); TA(T.T3, BQ * D); TA(T.hs, BQ * D);
+    TA(T.a_hat, BQ * A); TA(T.actions, BQ * A);
+    { float* t; TA(t, (BQ + 3) / 4 + 1); T.is_pad = reinterpret_cast<uint8_t*>(t); }
+    TA(T.losses, 4);
+    // backward scratch
+    const int64_t MN = (int64_t)B * N;
+    TA(T.gA, MN * D); TA(T.gB, MN * D); TA(T.gC, MN * D); TA(T.gH, MN * F); TA(T.gQKV, MN * 3 * D);
+    const int ldp = (N + 3) & ~3;
+    TA(T.Pbuf, (int64_t)B * H * N * ldp); TA(T.dPbuf, (int64_t)B * H * N * ldp); TA(T.delta, (int64_t)B * H * N);
+    TA(T.dXg, (int64_t)B * (C * ctx->P_ > Q ? C * ctx->P_ : Q) * D);
+    TA(T.tmp2BD, (int64_t)2 * B * D); TA(T.tmpD, 4 * D); TA(T.dqb, BQ * D);
+    {
+        std::vector<int> rows(2 * B);
+        for (int b = 0; b < B; ++b) { rows[2 * b] = b * N; rows[2 * b + 1] = b * N + 1; }
+        float* t; TA(t, 2 * B); T.pos_rows = reinterpret_cast<int*>(t);
+        if (hipMemcpy(T.pos_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "hipMemcpy failed"; return ACTMI_E_LAUNCH; }
+        // note: rows are for the max batch layout; entries b < B_call are valid for any smaller batch too
+    }
+#undef TA
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// forward (training)
+// ----------------------------------------------------------------------------------------------------------------------
+
+int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt, const float* actions, const uint8_t* is_pad,
+                  const float* eps, uint64_t dropout_seed, float dropout_p, int B, float* losses, float* a_hat_out,
+                  float* mu_out, float* logvar_out, hipStream_t st) {
+    ctx->err.clear();
+    (void)dropout_seed;
+    if (!ctx->train) { ctx->err = "handle was created without enable_training"; return ACTMI_E_STATE; }
+    if (!ctx->finalized) { ctx->err = "forward before finalize"; return ACTMI_E_STATE; }
+    if (B < 1 || B > ctx->cfg.max_batch) { ctx->err = "batch exceeds max_batch"; return ACTMI_E_INVALID; }
+    if (dropout_p != 0.f) { ctx->err = "dropout_p != 0 is not supported by this build (train with dropout 0)"; return ACTMI_E_INVALID; }
+    TrainState& T = *ctx->train;
+    const actmi_config& g = ctx->cfg;
+    const int C = g.num_cams, D = g.hidden_dim, F = g.dim_feedforward, Q = g.num_queries, N = ctx->N, w0 = g.base_width,
+              L = g.latent_dim, A = g.action_dim, S = g.state_dim, hd = D / g.nheads;
+    T.B = B; T.fmt = fmt;
+    HIPCHK(hipMemcpyAsync(T.actions, actions, (size_t)B * Q * A * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(T.is_pad, is_pad, (size_t)B * Q, hipMemcpyDeviceToDevice, st));
+    T.qpos = qpos;
+
+    // ---- CVAE encoder (detr_vae.py:117-151)
+    if (g.has_cvae_encoder) {
+        if (!eps) { ctx->err = "eps is required (the reference draws it in reparametrize, detr_vae.py:19-22)"; return ACTMI_E_INVALID; }
+        HIPCHK(hipMemcpyAsync(T.eps, eps, (size_t)B * L * 4, hipMemcpyDeviceToDevice, st));
+        CHK(launch_cvae_maps(T.cmap, T.ckpm, T.is_pad, B, Q, st));
+        const int n = Q + 2;
+        CHK(launch_fill_rows(T.Xc, D, (int64_t)n * D, ctx->P("cls_embed.weight"), 0, B, D, st));
+        CHK(launch_small_linear(qpos, S, ctx->P("encoder_joint_proj.weight"), ctx->P("encoder_joint_proj.bias"), T.Xc + D,
+                                (int64_t)n * D, B, D, S, st));
+        GemmArgs ap = G0();
+        ap.A = T.actions; ap.lda = A; ap.M = B * Q; ap.K = A; ap.Bw = ctx->P("encoder_action_proj.weight"); ap.ldb = A; ap.N = D;
+        ap.bias = ctx->P("encoder_action_proj.bias"); ap.C = T.Xc; ap.ldc = D; ap.rowmap = T.cmap;
+        CHK(launch_gemm(ap, st, &ctx->err));
+        for (int l = 0; l < g.enc_layers; ++l) {
+            float* out = (l + 1 < g.enc_layers) ? T.cv[l + 1].x_in : T.cv_out;
+            CHK(enc_fwd(ctx, ctx->cvae[l], T.cv[l], out, ctx->P("pos_table"), B, n, T.ckpm, st));
+        }
+        CHK(lin_fwd(ctx, T.cv_out, (int64_t)n * D, B, D, ctx->P("latent_proj.weight"), 2 * L, ctx->P("latent_proj.bias"),
+                    T.latent_info, 2 * L, nullptr, 0, st));
+        CHK(launch_reparam(T.latent_info, T.eps, T.z, mu_out, logvar_out, B, L, st));
+        CHK(launch_small_linear(T.z, L, ctx->P("latent_out_proj.weight"), ctx->P("latent_out_proj.bias"), ctx->X,
+                                (int64_t)N * D, B, D, L, st));
+    } else {
+        CHK(launch_fill_rows(ctx->X, D, (int64_t)N * D, ctx->P("latent_out_proj.bias"), 0, B, D, st));
+    }
+
+    // ---- backbone with saved maps
+    CHK(launch_normalize_pad(image, fmt, ctx->lut, T.xn4, B, C, g.image_h, g.image_w, st));
+    {
+        Conv1Args c1;
+        c1.image = image; c1.fmt = fmt; c1.lut = ctx->lut; c1.w = ctx->conv1_w; c1.scale = ctx->conv1_scale;
+        c1.bias = ctx->conv1_bias; c1.out = ctx->act1; c1.B = B; c1.C = C; c1.H = g.image_h; c1.W = g.image_w;
+        c1.Ho = ctx->H1; c1.Wo = ctx->W1; c1.Cout = w0;
+        CHK(launch_conv1(c1, st, &ctx->err));
+        CHK(launch_maxpool(ctx->act1, T.pool, C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
+    }
+    auto run_conv = [&](const ConvLayer& cl, const float* in, float* out, const float* res, int relu) -> int {
+        GemmArgs a = G0();
+        a.mode = 1;
+        a.A = in; a.H = cl.H; a.W = cl.W; a.Cin = cl.cin; a.KH = a.KW = cl.k; a.stride = cl.stride; a.pad = cl.pad;
+        a.Ho = cl.Ho; a.Wo = cl.Wo; a.img_stride = (int64_t)cl.H * cl.W * cl.cin;
+        a.M = B * cl.Ho * cl.Wo; a.N = cl.cout; a.K = cl.K;
+        a.Bw = cl.w; a.ldb = cl.K; a.scale = cl.scale; a.bias = cl.bias; a.res = res; a.ldres = cl.cout; a.relu = relu;
+        a.C = out; a.ldc = cl.cout; a.groups = C;
+        a.gA = (int64_t)B * cl.H * cl.W * cl.cin; a.gB = (int64_t)cl.cout * cl.K; a.gSB = cl.cout;
+        a.gC = (int64_t)a.M * cl.cout; a.gRes = a.gC;
+        return launch_gemm(a, st, &ctx->err);
+    };
+    const float* x = T.pool;
+    for (auto& bs : T.blocks) {
+        CHK(run_conv(ctx->convs[bs.c1], x, bs.y1, nullptr, 1));
+        const float* idt = x;
+        if (bs.ds >= 0) {
+            CHK(run_conv(ctx->convs[bs.ds], x, T.gbuf[0], nullptr, 0));
+            idt = T.gbuf[0];
+        }
+        CHK(run_conv(ctx->convs[bs.c2], bs.y1, bs.out, idt, 1));
+        x = bs.out;
+    }
+    if (ctx->rowmap_B != B) {
+        CHK(launch_build_rowmap(ctx->rowmap, B, C, ctx->fh, ctx->fw, N, st));
+        ctx->rowmap_B = B;
+    }
+    {
+        GemmArgs ip = G0();
+        ip.A = x; ip.lda = 8 * w0; ip.M = C * B * ctx->P_; ip.K = 8 * w0; ip.Bw = ctx->P("input_proj.weight"); ip.ldb = 8 * w0;
+        ip.N = D; ip.bias = ctx->P("input_proj.bias"); ip.C = ctx->X; ip.ldc = D; ip.rowmap = ctx->rowmap;
+        CHK(launch_gemm(ip, st, &ctx->err));
+    }
+    CHK(launch_small_linear(qpos, S, ctx->P("input_proj_robot_state.weight"), ctx->P("input_proj_robot_state.bias"),
+                            ctx->X + D, (int64_t)N * D, B, D, S, st));
+
+    // ---- encoder
+    for (int l = 0; l < g.enc_layers; ++l) {
+        float* out = (l + 1 < g.enc_layers) ? T.en[l + 1].x_in : T.mem;
+        CHK(enc_fwd(ctx, ctx->enc[l], T.en[l], out, ctx->pos_tokens, B, N, nullptr, st));
+    }
+
+    // ---- decoder layer 0 (transformer.py:274-295 with tgt = 0) + final norm + head
+    const DecW& d = ctx->dec[0];
+    CHK(lin_fwd(ctx, d.self_attn.in_b + 2 * D, D, 1, D, d.self_attn.out_w, D, d.self_attn.out_b, T.sa_tmp, D, nullptr, 0, st));
+    CHK(launch_layernorm(T.sa_tmp, nullptr, 0, d.n1w, d.n1b, nullptr, nullptr, T.t1, 1, D, 1e-5f, st, &ctx->err));
+    {
+        // qin = query_embed + t1 (materialised: it is the x operand of the q weight gradient), q = qin Wq^T + bq
+        HIPCHK(hipMemcpyAsync(T.qin, ctx->P("query_embed.weight"), (size_t)Q * D * 4, hipMemcpyDeviceToDevice, st));
+        CHK(launch_bcast_add_rows(T.qin, T.t1, Q, D, st));
+        CHK(lin_fwd(ctx, T.qin, D, Q, D, d.cross.in_w, D, d.cross.in_b, T.dq, D, nullptr, 0, st));
+    }
+    {
+        GemmArgs kv = G0();
+        kv.A = T.mem; kv.lda = D; kv.M = B * N; kv.K = D; kv.Bw = d.cross.in_w + (int64_t)D * D; kv.ldb = D; kv.N = 2 * D;
+        kv.bias = d.cross.in_b + D; kv.C = T.KV; kv.ldc = 2 * D;
+        kv.A_add = ctx->pos_tokens; kv.ld_add = D; kv.add_mod = N; kv.add_ncols = D;
+        CHK(launch_gemm(kv, st, &ctx->err));
+        AttnArgs at;
+        memset(&at, 0, sizeof(at));
+        at.Q = T.dq; at.q_bs = 0; at.q_rs = D;
+        at.K = T.KV; at.k_bs = (int64_t)N * 2 * D; at.k_rs = 2 * D;
+        at.V = T.KV + D; at.v_bs = at.k_bs; at.v_rs = 2 * D;
+        at.O = T.Oc; at.o_bs = (int64_t)Q * D; at.o_rs = D; at.lse = T.lse_c;
+        at.B = B; at.H = g.nheads; at.Nq = Q; at.Nk = N; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
+        CHK(launch_attention(at, st, &ctx->err));
+    }
+    const int M = B * Q;
+    {
+        GemmArgs op = G0();
+        op.A = T.Oc; op.lda = D; op.M = M; op.K = D; op.Bw = d.cross.out_w; op.ldb = D; op.N = D; op.bias = d.cross.out_b;
+        op.C = T.Y2pre; op.ldc = D; op.res = T.t1; op.ldres = D; op.res_mod = 1;
+        CHK(launch_gemm(op, st, &ctx->err));
+    }
+    CHK(launch_layernorm(T.Y2pre, nullptr, 0, d.n2w, d.n2b, nullptr, nullptr, T.T2, M, D, 1e-5f, st, &ctx->err));
+    CHK(lin_fwd(ctx, T.T2, D, M, D, d.l1w, F, d.l1b, T.Hd, F, nullptr, 1, st));
+    CHK(lin_fwd(ctx, T.Hd, F, M, F, d.l2w, D, d.l2b, T.Y3pre, D, T.T2, 0, st));
+    CHK(launch_layernorm(T.Y3pre, nullptr, 0, d.n3w, d.n3b, nullptr, nullptr, T.T3, M, D, 1e-5f, st, &ctx->err));
+    CHK(launch_layernorm(T.T3, nullptr, 0, ctx->P("transformer.decoder.norm.weight"), ctx->P("transformer.decoder.norm.bias"),
+                         nullptr, nullptr, T.hs, M, D, 1e-5f, st, &ctx->err));
+    CHK(lin_fwd(ctx, T.hs, D, M, D, ctx->P("action_head.weight"), A, ctx->P("action_head.bias"), T.a_hat, A, nullptr, 0, st));
+    if (a_hat_out) HIPCHK(hipMemcpyAsync(a_hat_out, T.a_hat, (size_t)M * A * 4, hipMemcpyDeviceToDevice, st));
+    CHK(launch_losses(T.a_hat, T.actions, T.is_pad, g.has_cvae_encoder ? T.latent_info : nullptr, T.losses, B, Q, A, L,
+                      g.kl_weight, st));
+    if (losses) HIPCHK(hipMemcpyAsync(losses, T.losses, 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    T.have_forward = true;
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// backward
+// ----------------------------------------------------------------------------------------------------------------------
+
+int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
+    ctx->err.clear();
+    if (!ctx->train || !ctx->train->have_forward) { ctx->err = "backward before forward_train"; return ACTMI_E_STATE; }
+    TrainState& T = *ctx->train;
+    const actmi_config& g = ctx->cfg;
+    const int B = T.B, C = g.num_cams, D = g.hidden_dim, F = g.dim_feedforward, Q = g.num_queries, N = ctx->N,
+              w0 = g.base_width, L = g.latent_dim, A = g.action_dim, S = g.state_dim, hd = D / g.nheads, H = g.nheads;
+    auto Gp = [&](const float* p) { return T.gbase + (p - ctx->pbase); };
+    auto GP = [&](const char* key) { return T.gbase + (ctx->P(key) - ctx->pbase); };
+    const int M = B * Q;
+    const DecW& d = ctx->dec[0];
+
+    // ---- loss -> a_hat -> heads
+    float* d_ahat = T.gQKV;                 // scratch [M][A]
+    CHK(launch_l1_bwd(T.a_hat, T.actions, T.is_pad, d_ahat, B, Q, A, loss_scale, st));
+    float* dhs = T.gA;
+    CHK(lin_dgrad(ctx, d_ahat, A, M, A, ctx->P("action_head.weight"), D, dhs, D, nullptr, nullptr, st));
+    CHK(lin_wgrad(ctx, d_ahat, A, M, A, T.hs, D, D, nullptr, 0, GP("action_head.weight"), GP("action_head.bias"), st));
+    // decoder.norm, norm3
+    float* dT3 = T.gC;
+    CHK(launch_ln_bwd(T.T3, ctx->P("transformer.decoder.norm.weight"), dhs, nullptr, dT3, GP("transformer.decoder.norm.weight"),
+                      GP("transformer.decoder.norm.bias"), M, D, 1e-5f, st));
+    float* dY3 = T.gA;
+    CHK(launch_ln_bwd(T.Y3pre, d.n3w, dT3, nullptr, dY3, Gp(d.n3w), Gp(d.n3b), M, D, 1e-5f, st));
+    // FFN
+    CHK(lin_dgrad(ctx, dY3, D, M, D, d.l2w, F, T.gH, F, nullptr, T.Hd, st));
+    CHK(lin_wgrad(ctx, dY3, D, M, D, T.Hd, F, F, nullptr, 0, Gp(d.l2w), Gp(d.l2b), st));
+    float* dT2 = T.gC;
+    CHK(lin_dgrad(ctx, T.gH, F, M, F, d.l1w, D, dT2, D, dY3, nullptr, st));
+    CHK(lin_wgrad(ctx, T.gH, F, M, F, T.T2, D, D, nullptr, 0, Gp(d.l1w), Gp(d.l1b), st));
+    // norm2
+    float* dY2 = T.gA;
+    CHK(launch_ln_bwd(T.Y2pre, d.n2w, dT2, nullptr, dY2, Gp(d.n2w), Gp(d.n2b), M, D, 1e-5f, st));
+    // cross-attention out_proj; residual branch carries dt1 (broadcast row)
+    float* dOc = T.gC;
+    CHK(lin_dgrad(ctx, dY2, D, M, D, d.cross.out_w, D, dOc, D, nullptr, nullptr, st));
+    CHK(lin_wgrad(ctx, dY2, D, M, D, T.Oc, D, D, nullptr, 0, Gp(d.cross.out_w), Gp(d.cross.out_b), st));
+    float* dt1 = T.tmpD;                    // [D]
+    HIPCHK(hipMemsetAsync(T.tmpD, 0, 4 * D * sizeof(float), st));
+    CHK(launch_colsum(dY2, D, dt1, M, D, st));
+    // cross attention
+    float* dKV = T.gQKV;                    // [B*N][2D]
+    {
+        AttnBwd t;
+        memset(&t, 0, sizeof(t));
+        t.Q = T.dq; t.q_bs = 0; t.q_rs = D;
+        t.K = T.KV; t.k_bs = (int64_t)N * 2 * D; t.k_rs = 2 * D;
+        t.V = T.KV + D; t.v_bs = t.k_bs; t.v_rs = 2 * D;
+        t.O = T.Oc; t.dO = dOc; t.lse = T.lse_c;
+        t.dQ = T.dqb; t.dq_bs = (int64_t)Q * D; t.dq_rs = D;
+        t.dK = dKV; t.dk_bs = (int64_t)N * 2 * D; t.dk_rs = 2 * D;
+        t.dV = dKV + D; t.dv_bs = t.dk_bs; t.dv_rs = 2 * D;
+        t.B = B; t.H = H; t.Nq = Q; t.Nk = N; t.HD = hd;
+        CHK(attn_bwd(ctx, t, st));
+    }
+    // q = (query_embed + t1) Wq^T + bq  (shared over the batch)
+    float* ddq = T.gA;                      // [Q][D]
+    CHK(launch_sum_batch(T.dqb, (int64_t)Q * D, D, ddq, B, Q, D, 0, st));
+    float* dqin = T.gC;                     // [Q][D]
+    CHK(lin_dgrad(ctx, ddq, D, Q, D, d.cross.in_w, D, dqin, D, nullptr, nullptr, st));
+    CHK(lin_wgrad(ctx, ddq, D, Q, D, T.qin, D, D, nullptr, 0, Gp(d.cross.in_w), Gp(d.cross.in_b), st));
+    CHK(launch_axpy(GP("query_embed.weight"), dqin, (int64_t)Q * D, st));
+    CHK(launch_colsum(dqin, D, dt1, Q, D, st));
+    // t1 = norm1(out_proj(b_v) + b_o)
+    float* dsa = T.tmpD + D;
+    CHK(launch_ln_bwd(T.sa_tmp, d.n1w, dt1, nullptr, dsa, Gp(d.n1w), Gp(d.n1b), 1, D, 1e-5f, st));
+    float* dbv = T.tmpD + 2 * D;
+    CHK(lin_dgrad(ctx, dsa, D, 1, D, d.self_attn.out_w, D, dbv, D, nullptr, nullptr, st));
+    CHK(lin_wgrad(ctx, dsa, D, 1, D, d.self_attn.in_b + 2 * D, D, D, nullptr, 0, Gp(d.self_attn.out_w), Gp(d.self_attn.out_b), st));
+    CHK(launch_axpy(Gp(d.self_attn.in_b) + 2 * D, dbv, D, st));
+    // k = (memory + pos) Wk^T, v = memory Wv^T
+    float* dmem = T.gB;
+    CHK(lin_dgrad(ctx, dKV, 2 * D, B * N, 2 * D, d.cross.in_w + (int64_t)D * D, D, dmem, D, nullptr, nullptr, st));
+    CHK(lin_wgrad(ctx, dKV, 2 * D, B * N, D, T.mem, D, D, ctx->pos_tokens, N, Gp(d.cross.in_w) + (int64_t)D * D, nullptr, st));
+    CHK(lin_wgrad(ctx, dKV + D, 2 * D, B * N, D, T.mem, D, D, nullptr, 0, Gp(d.cross.in_w) + (int64_t)2 * D * D, nullptr, st));
+    CHK(launch_colsum(dKV, 2 * D, Gp(d.cross.in_b) + D, B * N, 2 * D, st));
+    float* dpos2 = GP("additional_pos_embed.weight");
+    {
+        GemmArgs a = G0();
+        a.A = dKV; a.lda = 2 * D; a.a_rowmap = T.pos_rows; a.M = 2 * B; a.K = D; a.Bw = d.cross.in_w + (int64_t)D * D; a.ldb = D;
+        a.tb = 1; a.N = D; a.C = T.tmp2BD; a.ldc = D;
+        CHK(launch_gemm(a, st, &ctx->err));
+        CHK(launch_sum_batch(T.tmp2BD, 2 * D, D, dpos2, B, 2, D, 1, st));
+    }
+    // ---- encoder layers, last to first.  dOut lives in gB; each layer returns its dIn in gB again.
+    for (int l = g.enc_layers - 1; l >= 0; --l)
+        CHK(enc_bwd(ctx, ctx->enc[l], T.en[l], T.gB, T.gB, ctx->pos_tokens, B, N, nullptr, dpos2, st));
+    float* dX = T.gB;                       // grad wrt the token matrix [B][N][D]
+    // token 1: proprio = W_s qpos + b_s
+    CHK(launch_small_linear_wgrad(dX + D, (int64_t)N * D, T.qpos, S, GP("input_proj_robot_state.weight"), B, D, S, st));
+    CHK(launch_colsum(dX + D, (int64_t)N * D, GP("input_proj_robot_state.bias"), B, D, st));
+    // token 0: latent_input = W_lo z + b_lo
+    if (g.has_cvae_encoder) {
+        CHK(launch_small_linear_wgrad(dX, (int64_t)N * D, T.z, L, GP("latent_out_proj.weight"), B, D, L, st));
+        CHK(lin_dgrad(ctx, dX, (int64_t)N * D, B, D, ctx->P("latent_out_proj.weight"), L, T.dz, L, nullptr, nullptr, st));
+    }
+    CHK(launch_colsum(dX, (int64_t)N * D, GP("latent_out_proj.bias"), B, D, st));
+    // tokens 2..: input_proj (1x1 conv) of the layer4 maps
+    const int MP = C * B * ctx->P_;
+    CHK(launch_gather_rows(dX, ctx->rowmap, T.dXg, MP, D, st));
+    const BlockSave& last = T.blocks.back();
+    float* gcur = T.gbuf[0];                // grad wrt the current block output
+    CHK(lin_dgrad(ctx, T.dXg, D, MP, D, ctx->P("input_proj.weight"), 8 * w0, gcur, 8 * w0, nullptr, nullptr, st));
+    CHK(lin_wgrad(ctx, T.dXg, D, MP, D, last.out, 8 * w0, 8 * w0, nullptr, 0, GP("input_proj.weight"), GP("input_proj.bias"), st));
+
+    // ---- backbone: BasicBlocks in reverse.  Frozen BN: y = conv * scale + bias  =>  dconv = dy * scale.
+    for (size_t li = 0; li < ctx->convs.size(); ++li) {
+        const ConvLayer& cl = ctx->convs[li];
+        HIPCHK(hipMemsetAsync(T.conv_gw[li], 0, (size_t)C * cl.cout * cl.K * 4, st));
+        CHK(launch_repack_dgrad_w(cl.w, T.conv_wd[li], C, cl.cout, cl.cin, cl.k * cl.k, st));
+    }
+    HIPCHK(hipMemsetAsync(T.conv1_gw, 0, (size_t)C * w0 * 196 * 4, st));
+    float* dz = T.gbuf[1];
+    float* dzs = T.gbuf[2];
+    float* dsc = T.gbuf[3];
+    for (int bi = (int)T.blocks.size() - 1; bi >= 0; --bi) {
+        const BlockSave& bs = T.blocks[bi];
+        const ConvLayer& k1 = ctx->convs[bs.c1];
+        const ConvLayer& k2 = ctx->convs[bs.c2];
+        const float* x = bi > 0 ? T.blocks[bi - 1].out : T.pool;
+        const int64_t per = (int64_t)B * k2.Ho * k2.Wo * k2.cout;
+        // dz = dout * (out > 0) ; dzs = dz * scale_bn2 ; (downsample) dsc = dz * scale_ds
+        CHK(launch_relu_bn_bwd(gcur, nullptr, bs.out, k2.scale, dz, dzs, C, per, k2.cout, st));
+        CHK(conv_wgrad(ctx, k2, bs.c2, dzs, bs.y1, B, st));
+        // d(pre-bn1) = dgrad_conv2(dzs) * (y1 > 0) * scale_bn1
+        CHK(conv_dgrad(ctx, k2, bs.c2, dzs, dsc, nullptr, bs.y1, k1.scale, B, st));
+        CHK(conv_wgrad(ctx, k1, bs.c1, dsc, x, B, st));
+        // dx = dgrad_conv1(dsc) + identity path
+        float* dx = gcur;                     // gcur (dout) is dead after relu_bn_bwd
+        if (bs.ds < 0) {
+            CHK(conv_dgrad(ctx, k1, bs.c1, dsc, dx, dz, nullptr, nullptr, B, st));
+        } else {
+            const ConvLayer& ds = ctx->convs[bs.ds];
+            CHK(conv_dgrad(ctx, k1, bs.c1, dsc, dx, nullptr, nullptr, nullptr, B, st));
+            CHK(launch_relu_bn_bwd(dz, nullptr, nullptr, ds.scale, nullptr, dzs, C, per, ds.cout, st));   // dzs = dz * scale_ds
+            CHK(conv_wgrad(ctx, ds, bs.ds, dzs, x, B, st));
+            CHK(conv_dgrad(ctx, ds, bs.ds, dzs, dx, dx, nullptr, nullptr, B, st));
+        }
+    }
+    // stem: maxpool, relu, bn1, conv1 weight gradient through the NHWC4 normalised image
+    CHK(launch_maxpool_bwd(ctx->act1, gcur, T.g_act1, C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
+    CHK(launch_relu_bn_bwd(T.g_act1, nullptr, ctx->act1, ctx->conv1_scale, nullptr, T.g_act1, C,
+                           (int64_t)B * ctx->H1 * ctx->W1 * w0, w0, st));
+    {
+        GemmArgs a = G0();
+        a.A = T.g_act1; a.lda = w0; a.ta = 1; a.M = w0; a.K = B * ctx->H1 * ctx->W1;
+        a.Bw = T.xn4; a.tb = 2; a.N = 196; a.H = g.image_h; a.W = g.image_w; a.Cin = 4; a.KH = a.KW = 7; a.stride = 2; a.pad = 3;
+        a.Ho = ctx->H1; a.Wo = ctx->W1; a.img_stride = (int64_t)g.image_h * g.image_w * 4;
+        a.C = T.conv1_gw; a.ldc = 196; a.groups = C;
+        a.gA = (int64_t)B * ctx->H1 * ctx->W1 * w0; a.gB = (int64_t)B * g.image_h * g.image_w * 4; a.gC = (int64_t)w0 * 196;
+        a.splitk = pick_splitk(w0, 196, C, a.K);
+        if (a.splitk <= 1) { a.splitk = 0; a.res = a.C; a.ldres = 196; a.gRes = a.gC; }
+        CHK(launch_gemm(a, st, &ctx->err));
+    }
+    // packed conv gradients -> OIHW state_dict gradients
+    for (int cam = 0; cam < C; ++cam) {
+        const std::string p = "backbones." + std::to_string(cam) + ".0.body.";
+        CHK(launch_unpack_wgrad(T.conv1_gw + (int64_t)cam * w0 * 196, GP((p + "conv1.weight").c_str()), w0, 3, 7, 7, 196, 4, st));
+        for (size_t li = 0; li < ctx->convs.size(); ++li) {
+            const ConvLayer& cl = ctx->convs[li];
+            CHK(launch_unpack_wgrad(T.conv_gw[li] + (int64_t)cam * cl.cout * cl.K, GP((p + cl.name + ".weight").c_str()), cl.cout,
+                                    cl.cin, cl.k, cl.k, cl.K, cl.cin, st));
+        }
+    }
+
+    // ---- CVAE encoder
+    if (g.has_cvae_encoder) {
+        const int n = Q + 2;
+        // d latent_info from the reparametrisation and the KL term
+        CHK(launch_reparam_kl_bwd(T.latent_info, T.eps, T.dz, T.d_latent_info, B, L, g.kl_weight * loss_scale, st));
+        float* dcv = T.gB;                   // grad wrt the CVAE encoder output [B][n][D]: only the CLS rows are non-zero
+        HIPCHK(hipMemsetAsync(dcv, 0, (size_t)B * n * D * 4, st));
+        CHK(lin_dgrad(ctx, T.d_latent_info, 2 * L, B, 2 * L, ctx->P("latent_proj.weight"), D, dcv, (int64_t)n * D, nullptr, nullptr, st));
+        CHK(lin_wgrad(ctx, T.d_latent_info, 2 * L, B, 2 * L, T.cv_out, (int64_t)n * D, D, nullptr, 0, GP("latent_proj.weight"),
+                      GP("latent_proj.bias"), st));
+        for (int l = g.enc_layers - 1; l >= 0; --l)
+            CHK(enc_bwd(ctx, ctx->cvae[l], T.cv[l], T.gB, T.gB, ctx->P("pos_table"), B, n, T.ckpm, nullptr, st));
+        float* dXc = T.gB;
+        CHK(launch_sum_batch(dXc, (int64_t)n * D, D, GP("cls_embed.weight"), B, 1, D, 1, st));
+        CHK(launch_small_linear_wgrad(dXc + D, (int64_t)n * D, T.qpos, S, GP("encoder_joint_proj.weight"), B, D, S, st));
+        CHK(launch_colsum(dXc + D, (int64_t)n * D, GP("encoder_joint_proj.bias"), B, D, st));
+        CHK(launch_gather_rows(dXc, T.cmap, T.dXg, B * Q, D, st));
+        CHK(lin_wgrad(ctx, T.dXg, D, B * Q, D, T.actions, A, A, nullptr, 0, GP("encoder_action_proj.weight"),
+                      GP("encoder_action_proj.bias"), st));
+    }
+    T.have_forward = false;
+    return 0;
+}
+
+int train_zero_grad(actmi_ctx* ctx, hipStream_t st) {
+    if (!ctx->train) { ctx->err = "handle was created without enable_training"; return ACTMI_E_STATE; }
+    HIPCHK(hipMemsetAsync(ctx->train->gbase, 0, (size_t)ctx->ptotal * 4, st));
+    return 0;
+}
+
+int train_adamw_step(actmi_ctx* ctx, float lr, float lr_backbone, float wd, float b1, float b2, float eps, int64_t step,
+                     hipStream_t st) {
+    if (!ctx->train) { ctx->err = "handle was created without enable_training"; return ACTMI_E_STATE; }
+    TrainState& T = *ctx->train;
+    CHK(launch_adamw(ctx->pbase, T.gbase, T.mbase, T.vbase, T.group, ctx->ptotal, lr, lr_backbone, wd, b1, b2, eps, step, st));
+    return engine_prepare_weights(ctx, st);       // conv repack, decoder constants, learned pos rows follow the new weights
+}

@@ -24,6 +24,34 @@ class _LoadStatus:
         return f"_IncompatibleKeys(missing_keys={self.missing_keys}, unexpected_keys={self.unexpected_keys})"
 
 
+class _Loss(torch.Tensor):
+    """Scalar loss tensor whose ``backward()`` runs the library's backward pass (imitate_episodes.py:605-606)."""
+
+    @staticmethod
+    def wrap(t, policy):
+        out = t.detach().clone().as_subclass(_Loss)
+        out._policy = policy
+        return out
+
+    def backward(self, *a, **k):      # noqa: D401
+        self._policy.model.backward(1.0)
+
+
+class _AdamW:
+    """optimizer.zero_grad()/step() of the reference's two-group AdamW (detr/main.py:102-110) over libactmi."""
+
+    def __init__(self, engine, lr, lr_backbone, weight_decay):
+        self.engine, self.lr, self.lr_backbone, self.weight_decay = engine, lr, lr_backbone, weight_decay
+        self.t = 0
+
+    def zero_grad(self):
+        self.engine.zero_grad()
+
+    def step(self):
+        self.t += 1
+        self.engine.adamw_step(self.lr, self.lr_backbone, self.weight_decay, step=self.t)
+
+
 class ACTPolicy:
     """reference policy.py:243-348."""
 
@@ -39,18 +67,22 @@ class ACTPolicy:
         self.kl_weight = args_override["kl_weight"]
         self.vq = args_override.get("vq", False)
         mb = max_batch or int(args_override.get("max_batch", 8))
-        self.model = ACTEngine(self.cfg, max_batch=mb, device=device)
+        self.model = ACTEngine(self.cfg, max_batch=mb, device=device, training=bool(args_override.get("training", True)))
         # random init of the reference architecture (the ImageNet fetch of backbone.py:121-124 cannot run offline)
         from actmi.weights import generate_state_dict
         self.model.load_state_dict(generate_state_dict(self.cfg, seed=init_seed))
         self.training = True
-        self.optimizer = None
+        self.optimizer = _AdamW(self.model, args_override["lr"], args_override.get("lr_backbone", 1e-5), self.cfg.weight_decay)
+        self.train_dropout = float(args_override.get("train_dropout", 0.0))
         print(f"KL Weight {self.kl_weight}")
         print(f"Use Depth: {self.use_depth}")
 
     def __call__(self, qpos, image, actions=None, is_pad=None, vq_sample=None, depth_img=None, pointcloud=None):
-        if actions is not None:
-            raise NotImplementedError("training call (actions given) is not built in this version of libactmi")
+        if actions is not None:                                # training / validation (policy.py:288-320)
+            eps = getattr(self, "next_eps", None)
+            self.next_eps = None
+            out = self.model.forward_train(qpos, image, actions, is_pad, eps=eps, dropout_p=0.0)
+            return {"l1": out["l1"], "kl": out["kl"], "loss": _Loss.wrap(out["loss"], self)}
         # inference: ImageNet normalisation (policy.py:268-272) is fused into the conv1 loader
         return self.model.forward_infer(qpos, image)
 

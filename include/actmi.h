@@ -55,14 +55,17 @@ typedef struct actmi_config {
 typedef struct actmi_gemm_desc {
     const float* A;
     int64_t lda;
-    int32_t mode;              /* 0 = row-major A, 1 = NHWC implicit im2col, K index = (r*KW+s)*Cin+c */
+    /* A operand form.  0: row-major [M][K] (contraction contiguous).  1: NHWC implicit im2col (forward conv),
+     * K index = (r*KW+s)*Cin+c.  2: conv data-gradient gather: rows are INPUT pixels (b,hi,wi), A = dY NHWC
+     * [img][Ho][Wo][Cout], K index = (r*KW+s)*Cout+n.  (ta=1 selects the transposed form instead.) */
+    int32_t mode;
     int32_t H, W, Cin, KH, KW, stride, pad, Ho, Wo;
     int64_t img_stride;
     const float* A_add;        /* optional: A'[m][k] = A[m][k] + A_add[m % add_mod][k] for columns n < add_ncols */
     int64_t ld_add;
     int32_t add_mod;
     int32_t add_ncols;
-    const float* Bw;           /* [N][K] row-major (torch Linear layout) */
+    const float* Bw;           /* [N][K] row-major (torch Linear layout) unless tb */
     int64_t ldb;
     const float* scale;        /* per-n or NULL */
     const float* bias;         /* per-n or NULL */
@@ -76,6 +79,23 @@ typedef struct actmi_gemm_desc {
     int32_t M, N, K;
     int32_t groups;            /* blockIdx.z; per-group element offsets below */
     int64_t gA, gB, gSB, gC, gRes;
+    /* ---- extensions used by the backward pass ---- */
+    int32_t ta;                /* 1: A stored [K][M] (out index contiguous), lda = row stride of that storage */
+    int32_t tb;                /* 1: B stored [K][N]; 2: conv weight-gradient gather: B[(r,s,c)][m=(b,ho,wo)] read from
+                                  the NHWC input X (H,W,Cin,...,Ho,Wo describe the forward conv), out index = (r*KW+s)*Cin+c */
+    const int32_t* a_rowmap;   /* optional gather of A rows (mode 0, ta 0) */
+    const float* B_add;        /* tb=1 only: B'[k][n] = B[k][n] + B_add[k % badd_mod][n] */
+    int64_t ld_badd;
+    int32_t badd_mod;
+    int32_t splitk;            /* >1: contraction split over blockIdx.z, results atomically added into C (C pre-zeroed) */
+    const float* mask;         /* epilogue: v = 0 where mask[m][n] <= 0 (ReLU backward), same ld as C unless ldmask */
+    int64_t ldmask;
+    float* C2;                 /* optional second output C2[m][n] = v * scale2[n] (ld = ldc) */
+    const float* scale2;
+    float alpha;               /* acc multiplier; 0 means 1 */
+    int32_t groups_inner;      /* >0: group g = (g / groups_inner, g % groups_inner) with the second-level strides below */
+    int64_t gA2, gB2, gC2, gRes2;
+    int64_t gMask, gC2out;     /* per-group strides of mask / C2 (first level) */
 } actmi_gemm_desc;
 
 /* Multi-head attention descriptor: softmax(scale * q k^T [+ key padding mask]) v per (batch, head).

@@ -1,0 +1,179 @@
+"""Training path parity on the GPU: losses and EVERY parameter gradient against the golden fixtures produced by the
+reference's own modules (autograd of DETRVAE + ACTPolicy.__call__), and one AdamW step against torch.optim.AdamW
+with the reference's two parameter groups.  Tolerance: gradients are sums of O(1e4..1e6) fp32 products whose
+order differs from ATen's; bound = 2e-3 of the tensor's max |grad| (observed ~1e-5..1e-4), losses 1e-4 relative."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from helpers import load_fixture, regenerate, sample_like  # noqa: E402
+from actmi import weights as W  # noqa: E402
+from actmi import lib as L  # noqa: E402
+from actmi import ops  # noqa: E402
+from actmi.engine import ACTEngine  # noqa: E402
+
+
+def rel_err(got, exp):
+    got, exp = got.detach().cpu().double(), exp.detach().cpu().double()
+    return float((got - exp).abs().max() / (exp.abs().max() + 1e-30))
+
+
+def _gemm_desc(**kw):
+    d = L.GemmDesc()
+    for k, v in kw.items():
+        setattr(d, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    return d
+
+
+@pytest.mark.parametrize("M,N,K", [(77, 130, 96), (1202, 64, 1202), (16, 512, 800), (300, 36, 17)])
+def test_gemm_transposed_operand_forms(M, N, K):
+    """dX = dY W (B stored [K][N]) and dW = dY^T X (both stored [contraction][out])."""
+    g = torch.Generator().manual_seed(M + N)
+    d = torch.device("cuda:0")
+    A = torch.randn(M, K, generator=g).to(d)
+    Bkn = torch.randn(K, N, generator=g).to(d)
+    out = torch.zeros(M, N, device=d)
+    Kp = (K + 3) // 4 * 4
+    Apad = torch.zeros(M, Kp, device=d)
+    Apad[:, :K] = A
+    desc = _gemm_desc(A=Apad, lda=Kp, M=M, N=N, K=K, Bw=Bkn, ldb=N, tb=1, C=out, ldc=N, groups=1)
+    if N % 4 == 0:
+        L.check(L.load().actmi_op_gemm(C.byref(desc), L.current_stream_ptr()), None, "gemm NT")
+        assert rel_err(out, A.double() @ Bkn.double()) < 3e-6
+    # both transposed: C[m][n] = sum_k At[k][m] Bt[k][n]
+    Mp = (M + 3) // 4 * 4
+    At = torch.zeros(K, Mp, device=d)
+    At[:, :M] = A.t()
+    Np = (N + 3) // 4 * 4
+    Bt = torch.zeros(K, Np, device=d)
+    Bt[:, :N] = Bkn
+    out2 = torch.zeros(M, N, device=d)
+    desc = _gemm_desc(A=At, lda=Mp, ta=1, M=M, N=N, K=K, Bw=Bt, ldb=Np, tb=1, C=out2, ldc=N, groups=1)
+    L.check(L.load().actmi_op_gemm(C.byref(desc), L.current_stream_ptr()), None, "gemm TT")
+    assert rel_err(out2, A.double() @ Bkn.double()) < 3e-6
+    # split-K with atomics accumulates on top of existing values
+    out3 = torch.ones(M, N, device=d)
+    desc = _gemm_desc(A=At, lda=Mp, ta=1, M=M, N=N, K=K, Bw=Bt, ldb=Np, tb=1, C=out3, ldc=N, groups=1, splitk=3)
+    L.check(L.load().actmi_op_gemm(C.byref(desc), L.current_stream_ptr()), None, "gemm TT splitk")
+    assert rel_err(out3, A.double() @ Bkn.double() + 1.0) < 3e-6
+
+
+@pytest.mark.parametrize("G,B,H,W,Cin,Cout,k,stride,pad", [(2, 2, 12, 16, 8, 16, 3, 1, 1), (1, 2, 15, 20, 16, 32, 3, 2, 1),
+                                                          (2, 1, 16, 24, 16, 32, 1, 2, 0), (1, 1, 30, 40, 64, 64, 3, 1, 1)])
+def test_conv_dgrad_wgrad(G, B, H, W, Cin, Cout, k, stride, pad):
+    g = torch.Generator().manual_seed(H * 3 + Cin)
+    d = torch.device("cuda:0")
+    x = torch.randn(G, B, Cin, H, W, generator=g).double().requires_grad_(True)
+    w = (torch.randn(G, Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).double().requires_grad_(True)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    dy = torch.randn(G, B, Cout, Ho, Wo, generator=g).double()
+    for i in range(G):
+        F.conv2d(x[i], w[i], None, stride, pad).backward(dy[i])
+    dy_nhwc = dy.permute(0, 1, 3, 4, 2).contiguous().float().to(d)
+    x_nhwc = x.detach().permute(0, 1, 3, 4, 2).contiguous().float().to(d)
+    KK = k * k
+    # dgrad weights [G][Cin][(r,s,n)]
+    wd = w.detach().permute(0, 2, 3, 4, 1).contiguous().float().to(d)          # [G][Cin][k][k][Cout]
+    dx = torch.zeros(G, B, H, W, Cin, device=d)
+    desc = _gemm_desc(mode=2, A=dy_nhwc, H=H, W=W, Cin=Cin, KH=k, KW=k, stride=stride, pad=pad, Ho=Ho, Wo=Wo,
+                      img_stride=Ho * Wo * Cout, M=B * H * W, N=Cin, K=KK * Cout, Bw=wd, ldb=KK * Cout, C=dx, ldc=Cin,
+                      groups=G, gA=B * Ho * Wo * Cout, gB=Cin * KK * Cout, gC=B * H * W * Cin)
+    L.check(L.load().actmi_op_gemm(C.byref(desc), L.current_stream_ptr()), None, "dgrad")
+    assert rel_err(dx.permute(0, 1, 4, 2, 3), x.grad) < 3e-6
+    # wgrad [G][Cout][(r,s,c)] with split-K atomics
+    gw = torch.zeros(G, Cout, k, k, Cin, device=d)
+    desc = _gemm_desc(A=dy_nhwc, lda=Cout, ta=1, M=Cout, K=B * Ho * Wo, Bw=x_nhwc, tb=2, N=KK * Cin, H=H, W=W, Cin=Cin,
+                      KH=k, KW=k, stride=stride, pad=pad, Ho=Ho, Wo=Wo, img_stride=H * W * Cin, C=gw, ldc=KK * Cin,
+                      groups=G, gA=B * Ho * Wo * Cout, gB=B * H * W * Cin, gC=Cout * KK * Cin, splitk=2)
+    L.check(L.load().actmi_op_gemm(C.byref(desc), L.current_stream_ptr()), None, "wgrad")
+    assert rel_err(gw.permute(0, 1, 4, 2, 3), w.grad) < 3e-6
+
+
+def _run_training_fixture(name, check_all):
+    z, cfg = load_fixture(name)
+    sd_np, inp = regenerate(z, cfg)
+    B = int(z["batch"])
+    eng = ACTEngine(cfg, max_batch=B, training=True)
+    eng.load_state_dict(sd_np)
+    eng.finalize()
+    d = eng.device
+    out = eng.forward_train(torch.from_numpy(inp["qpos"]).to(d), torch.from_numpy(inp["image_u8"]).to(d),
+                            torch.from_numpy(inp["actions"]).to(d), torch.from_numpy(inp["is_pad"]).to(d),
+                            eps=torch.from_numpy(z["train.eps"]).to(d))
+    for k in ("l1", "kl", "loss"):
+        got, exp = float(out[k]), float(z["train." + k][0])
+        print(f"{name} {k}: hip {got:.6f} ref {exp:.6f}")
+        assert abs(got - exp) <= 1e-4 * max(1.0, abs(exp)), k
+    assert np.abs(out["a_hat"].cpu().numpy() - z["train.a_hat"]).max() <= 1e-4
+    assert np.abs(out["mu"].cpu().numpy() - z["train.mu"]).max() <= 1e-4
+    assert np.abs(out["logvar"].cpu().numpy() - z["train.logvar"]).max() <= 1e-4
+    eng.zero_grad()
+    eng.backward(1.0)
+    names = [str(n) for n in z["grad_names"]]
+    none = set(str(n) for n in z["grad_none"])
+    worst = (0.0, "")
+    for n, ref_l2 in zip(names, z["grad_l2"]):
+        g = eng.grad(n).cpu().double()
+        if n in none:
+            assert float(g.abs().max()) == 0.0, n            # is_pad_head: no gradient (quirk 3)
+            continue
+        got = float(g.norm())
+        if ref_l2 == 0.0:
+            assert got == 0.0, f"{n}: dead-layer gradient must be exactly zero (quirk 1)"
+            continue
+        if ref_l2 < 1e-6:
+            # mathematically zero (decoder layer-0 self-attention q/k/v weights on tgt = 0, quirk 2): the reference
+            # shows fp noise of ~1e-8 there, this implementation is exactly zero
+            assert got < 1e-6, (n, got, ref_l2)
+            continue
+        e = abs(got - ref_l2) / ref_l2
+        worst = max(worst, (e, n))
+        assert e <= 2e-3, (n, got, ref_l2)
+        key = "grad." + n
+        if key in z.files:
+            exp = z[key].reshape(-1)
+            gs = sample_like(g.float().numpy(), z)
+            assert np.abs(gs - exp).max() <= 2e-3 * max(np.abs(exp).max(), 1e-6), n
+    print(f"{name}: worst relative gradient-norm error {worst[0]:.2e} at {worst[1]}")
+    return eng, z, cfg, sd_np, inp
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_c3"])
+def test_training_step_matches_reference_gradients(name):
+    _run_training_fixture(name, True)
+
+
+def test_training_full_size_gradients_and_adamw():
+    """C=4, 480x640, B=2 (golden full4): losses, sampled gradients, gradient norms of all 640 parameters, then one
+    AdamW step against torch.optim.AdamW fed with the same gradients."""
+    eng, z, cfg, sd_np, inp = _run_training_fixture("full4", False)
+    keys = ["action_head.weight", "transformer.encoder.layers.1.linear1.weight", "transformer.decoder.layers.3.linear1.weight",
+            "backbones.2.0.body.layer3.0.conv1.weight", "backbones.0.0.body.conv1.weight", "is_pad_head.weight",
+            "encoder.layers.0.norm1.bias", "query_embed.weight"]
+    lr, lr_bb, wd = 1e-5, 1e-5 * 3, 1e-4
+    before = {k: torch.from_numpy(sd_np[k]).clone() for k in keys}
+    grads = {k: eng.grad(k).cpu() for k in keys}
+    eng.adamw_step(lr, lr_bb, wd, step=1)
+    after = eng.state_dict()
+    for k in keys:
+        p = before[k].clone().requires_grad_(True)
+        if k.startswith("is_pad_head"):
+            assert torch.equal(after[k], before[k])               # grad None in the reference => untouched
+            continue
+        opt = torch.optim.AdamW([p], lr=lr_bb if "backbone" in k else lr, weight_decay=wd)
+        p.grad = grads[k].clone()
+        opt.step()
+        err = float((after[k] - p.detach()).abs().max())
+        assert err <= 1e-7 + 1e-6 * float(p.detach().abs().max()), (k, err)
+    # dead decoder layer: zero gradient -> only the decoupled weight decay moved it
+    k = "transformer.decoder.layers.3.linear1.weight"
+    assert torch.allclose(after[k], before[k] * (1 - lr * wd), rtol=0, atol=1e-9)
+    # the inference path sees the updated weights (derived tensors were refreshed)
+    d = eng.device
+    a1 = eng.forward_infer(torch.from_numpy(inp["qpos"]).to(d), torch.from_numpy(inp["image_u8"]).to(d))
+    assert torch.isfinite(a1).all()
