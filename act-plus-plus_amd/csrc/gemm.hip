@@ -19,13 +19,15 @@
 // Planes are padded by one float4 so that the lanes writing one row's chunks hit different bank groups.
 #include "common.h"
 #include <cstdio>
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
 constexpr int BK = 32;
 constexpr int NPL = BK / 4;
 
-enum { A_N = 0, A_CONV = 1, A_DGRAD = 2, A_T = 3 };
+enum { A_N = 0, A_CONV = 1, A_DGRAD = 2, A_T = 3, A_NADD = 4 };   // A_NADD: A_N with the broadcast addend
 enum { B_N = 0, B_T = 1, B_WGRAD = 2 };
 
 template <int BM, int BN>
@@ -34,7 +36,7 @@ constexpr int stage_f4() { return NPL * ((BM + 1) + (BN + 1)); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int PSA = BM + 1, PSB = BN + 1;
@@ -53,8 +55,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
         const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
         bid = base + (bid >> 3);
     }
-    const int m0 = (bid / tiles_n) * BM;
-    const int n0 = (bid % tiles_n) * BN;
+    // grouped rasterisation: walk the tile grid in bands of GROUP_M tile rows, column by column, so that the ~64 tiles
+    // an XCD runs concurrently form a compact patch (8 A panels x 8 B panels) and re-use each other's operand panels
+    // in that XCD's 4 MB L2.  fp32 operands make the kernel L2/fabric-bandwidth sensitive (32 FLOP per loaded byte at
+    // a 128x128 tile), so the hit rate matters as much as the MFMA schedule.
+    constexpr int GROUP_M = 8;
+    const int width = GROUP_M * tiles_n;
+    const int group_id = bid / width;
+    const int first_m = group_id * GROUP_M;
+    const int gsz = (tiles_m - first_m < GROUP_M) ? tiles_m - first_m : GROUP_M;
+    const int in_group = bid - group_id * width;
+    const int m0 = (first_m + in_group % gsz) * BM;
+    const int n0 = (in_group / gsz) * BN;
     const int splitk = p.splitk > 1 ? p.splitk : 1;
     const int split = blockIdx.z % splitk;
     const int g = blockIdx.z / splitk;
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
     const float* add_ptr[NLA];
     int a_hi0[NLA], a_wi0[NLA];
     bool a_ok[NLA];
-    const bool use_add = (AMODE == A_N) && p.A_add != nullptr && n0 < p.add_ncols;
+    const bool use_add = (AMODE == A_NADD) && n0 < p.add_ncols;       // block-uniform
     // T-form micro tile of A: out group og (4 consecutive m), k group kg (4 consecutive k)
     const int a_og = t % (BM / 4), a_kg = t / (BM / 4);
     if (AMODE == A_T) {
@@ -101,10 +113,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
             const int mm = a_ok[i] ? m : 0;
             add_ptr[i] = nullptr;
             a_hi0[i] = a_wi0[i] = 0;
-            if (AMODE == A_N) {
+            if (AMODE == A_N || AMODE == A_NADD) {
                 const int64_t ar = p.a_rowmap ? p.a_rowmap[mm] : mm;
                 a_ptr[i] = A + ar * p.lda;
-                if (use_add) add_ptr[i] = p.A_add + (int64_t)(mm % p.add_mod) * p.ld_add;
+                if (AMODE == A_NADD) add_ptr[i] = p.A_add + (int64_t)(mm % p.add_mod) * p.ld_add;
             } else if (AMODE == A_CONV) {
                 const int hw = p.Ho * p.Wo;
                 const int b = mm / hw, rem = mm - b * hw;
@@ -142,10 +154,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
         wg_s = rs - wg_r * p.KW;
     }
 
-    f32x4 ra[NLA], rb[NLB];
+    // staging registers of the K tile in flight
+    struct Regs {
+        f32x4 ra[NLA], rb[NLB], rx[AMODE == A_NADD ? NLA : 1];
+        bool ra_ok[NLA], rb_ok[NLB];
+    };
+    Regs R0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, auto& R) {
         // ---------------- A
         if (AMODE == A_T) {
             if (a_kg < NPL) {
@@ -162,21 +179,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
                             for (int e = 0; e < 4; ++e) if (o + e < p.M) v[e] = src[e];
                         }
                     }
-                    ra[j] = v;
+                    R.ra[j] = v;
                 }
             }
         } else {
             const int k = kt * BK + cidx * 4;
             const bool kok = k < p.K;
-            if (AMODE == A_N) {
+            if (AMODE == A_N || AMODE == A_NADD) {
+                // branch-free: always load from a valid address, zero by select afterwards (keeps the K loop one
+                // basic block so that the loads interleave with the MFMA stream)
+                const int kc = kok ? k : 0;
 #pragma unroll
                 for (int i = 0; i < NLA; ++i) {
-                    f32x4 v = zero4;
-                    if (a_ok[i] && kok) {
-                        v = ld4(a_ptr[i] + k);
-                        if (use_add) v += ld4(add_ptr[i] + k);
-                    }
-                    ra[i] = v;
+                    R.ra[i] = ld4(a_ptr[i] + kc);
+                    if (AMODE == A_NADD) R.rx[i] = ld4(add_ptr[i] + kc);
+                    R.ra_ok[i] = a_ok[i] && kok;
                 }
             } else if (AMODE == A_CONV) {
                 const int rs = k / p.Cin;
@@ -186,10 +203,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
 #pragma unroll
                 for (int i = 0; i < NLA; ++i) {
                     const int hi = a_hi0[i] + r, wi = a_wi0[i] + s;
-                    f32x4 v = zero4;
-                    if (a_ok[i] && kok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                        v = ld4(a_ptr[i] + ((int64_t)hi * p.W + wi) * p.Cin + c);
-                    ra[i] = v;
+                    const bool inb = a_ok[i] && kok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                    const int64_t off = inb ? ((int64_t)hi * p.W + wi) * p.Cin + c : 0;
+                    R.ra[i] = ld4(a_ptr[i] + off);
+                    R.ra_ok[i] = inb;
                 }
             } else {   // A_DGRAD: contraction (r, s, n) over the forward output channels
                 const int Cq = p.K / (p.KH * p.KW);
@@ -206,7 +223,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
                         if (ho * p.stride == hn && wo * p.stride == wn && ho < p.Ho && wo < p.Wo)
                             v = ld4(a_ptr[i] + ((int64_t)ho * p.Wo + wo) * Cq + n);
                     }
-                    ra[i] = v;
+                    R.ra[i] = v;
                 }
             }
         }
@@ -214,11 +231,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
         if (BMODE == B_N) {
             const int k = kt * BK + cidx * 4;
             const bool kok = k < p.K;
+            const int kc = kok ? k : 0;
 #pragma unroll
             for (int i = 0; i < NLB; ++i) {
-                f32x4 v = zero4;
-                if (b_ok[i] && kok) v = ld4(b_ptr[i] + k);
-                rb[i] = v;
+                R.rb[i] = ld4(b_ptr[i] + kc);
+                R.rb_ok[i] = b_ok[i] && kok;
             }
         } else if (BMODE == B_T) {
             if (b_kg < NPL) {
@@ -238,7 +255,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
                             for (int e = 0; e < 4; ++e) if (o + e < p.N) v[e] = src[e] + (ad ? ad[e] : 0.f);
                         }
                     }
-                    rb[j] = v;
+                    R.rb[j] = v;
                 }
             }
         } else {   // B_WGRAD: B[(r,s,c)][m] gathered from the forward conv's NHWC input
@@ -256,34 +273,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
                         if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
                             v = ld4(Bw + (int64_t)b * p.img_stride + ((int64_t)hi * p.W + wi) * p.Cin + wg_c);
                     }
-                    rb[j] = v;
+                    R.rb[j] = v;
                 }
             }
         }
     };
-    auto store_tile = [&](int stage) {
+    auto store_tile = [&](int stage, auto& R) {
         f32x4* sa = smem + stage * STAGE;
         f32x4* sb = sa + NPL * PSA;
         if (AMODE == A_T) {
             if (a_kg < NPL) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 v = {ra[0][i], ra[1][i], ra[2][i], ra[3][i]};
+                    const f32x4 v = {R.ra[0][i], R.ra[1][i], R.ra[2][i], R.ra[3][i]};
                     sa[a_kg * PSA + a_og * 4 + i] = v;
                 }
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NLA; ++i) sa[cidx * PSA + srow + 32 * i] = ra[i];
+            for (int i = 0; i < NLA; ++i) {
+                f32x4 v = R.ra[i];
+                if (AMODE == A_NADD) { if (use_add) v += R.rx[i]; }
+                if (AMODE != A_DGRAD) v = R.ra_ok[i] ? v : zero4;
+                sa[cidx * PSA + srow + 32 * i] = v;
+            }
         }
         if (BMODE == B_N) {
 #pragma unroll
-            for (int i = 0; i < NLB; ++i) sb[cidx * PSB + srow + 32 * i] = rb[i];
+            for (int i = 0; i < NLB; ++i) sb[cidx * PSB + srow + 32 * i] = R.rb_ok[i] ? R.rb[i] : zero4;
         } else {
             if (b_kg < NPL) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 v = {rb[0][i], rb[1][i], rb[2][i], rb[3][i]};
+                    const f32x4 v = {R.rb[0][i], R.rb[1][i], R.rb[2][i], R.rb[3][i]};
                     sb[b_kg * PSB + b_og * 4 + i] = v;
                 }
             }
@@ -298,32 +320,77 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    load_tile(kt_begin);
-    store_tile(0);
+    const int nsteps = kt_end - kt_begin;
+    load_tile(kt_begin, R0);
+    store_tile(0, R0);
     __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
-        const bool more = kt + 1 < kt_end;
-        if (more) load_tile(kt + 1);
+    // One K step.  PF = prefetch the next tile: the global loads are issued right after the first fragment reads
+    // so that (with the branch-free loaders) they sit in the same basic block as the MFMAs and interleave with them;
+    // the LDS stores of the next stage follow the last MFMA group.  The final step is peeled (PF = false).
+    // step s computes LDS stage s&1 while the global loads of tile s+1 are in flight (issued in the shadow of the first
+    // MFMAs), then stores that tile into the other stage.  (A two-step-deep register prefetch was measured: no gain --
+    // the loop is bound by the CU's L1 fill rate, ~8 B/clk at a 128x128 fp32 tile, not by load latency.)
+    auto kstep = [&](int s_, auto par, auto pf) {
+        constexpr bool PF = decltype(pf)::value;
+        constexpr int cur = decltype(par)::value;
+        const int kt = kt_begin + s_;
         const f32x4* sa = smem + cur * STAGE;
         const f32x4* sb = sa + NPL * PSA;
+        f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int kb = 0; kb < NPL / 2; ++kb) {
-            f32x4 af[TM], bf[TN];
+        for (int i = 0; i < TM; ++i) af[0][i] = sa[lh * PSA + wrow0 + i * 32 + li];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = sa[(2 * kb + lh) * PSA + wrow0 + i * 32 + li];
+        for (int j = 0; j < TN; ++j) bf[0][j] = sb[lh * PSB + wcol0 + j * 32 + li];
+        constexpr bool HOT = (AMODE == A_N || AMODE == A_NADD || AMODE == A_CONV) && BMODE == B_N;
+        if (PF) load_tile(kt + 1, R0);
+        auto kblock = [&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            if (kb + 1 < NPL / 2) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = sb[(2 * kb + lh) * PSB + wcol0 + j * 32 + li];
+                for (int i = 0; i < TM; ++i) af[(kb + 1) & 1][i] = sa[(2 * (kb + 1) + lh) * PSA + wrow0 + i * 32 + li];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[(kb + 1) & 1][j] = sb[(2 * (kb + 1) + lh) * PSB + wcol0 + j * 32 + li];
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-        }
-        if (more) store_tile(cur ^ 1);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kb & 1][i][e], bf[kb & 1][j][e], acc[i][j], 0, 0, 0);
+            if (HOT) {
+                // issue order inside this k-block: each 64-cycle MFMA is followed by a few address/VALU ops, at most one
+                // global load of the next tile and one LDS fragment read of the next k-block (they run in the MFMA's shadow)
+#pragma unroll
+                for (int r = 0; r < 4 * TM * TN; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x006, kb == 0 ? 10 : 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        kblock(std::integral_constant<int, 0>{});
+        kblock(std::integral_constant<int, 1>{});
+        kblock(std::integral_constant<int, 2>{});
+        kblock(std::integral_constant<int, 3>{});
+        static_assert(NPL / 2 == 4, "k-block unroll assumes BK = 32");
+        if (PF) store_tile(cur ^ 1, R0);
         __syncthreads();
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int s_ = 0;
+    for (; s_ + 2 < nsteps; s_ += 2) {
+        kstep(s_, P0{}, std::true_type{});
+        kstep(s_ + 1, P1{}, std::true_type{});
+    }
+    if (nsteps - s_ == 2) {
+        kstep(s_, P0{}, std::true_type{});
+        kstep(s_ + 1, P1{}, std::false_type{});
+    } else {
+        kstep(s_, P0{}, std::false_type{});
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -335,6 +402,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
     float* C = p.C + offC;
     float* C2 = p.C2 ? p.C2 + (int64_t)g * p.gC2out : nullptr;
     const float alpha = p.alpha != 0.f ? p.alpha : 1.f;
+    const bool has_res = res != nullptr, has_mask = mask != nullptr, has_map = p.rowmap != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wcol0 + j * 32 + li;
@@ -344,24 +412,42 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
         const float sc2 = (C2 && nok) ? p.scale2[(int64_t)g * p.gSB + n] : 1.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            // phase A: row indices (row-map loads batched)
+            int orow[16];
+            bool ok[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wrow0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (nok && m < p.M) {
+                ok[e] = nok && m < p.M;
+                orow[e] = m;
+                if (has_map && ok[e]) orow[e] = p.rowmap[m];
+            }
+            // phase B: residual / mask loads, all in flight together
+            float rv[16], mv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wrow0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                rv[e] = 0.f;
+                mv[e] = 1.f;
+                if (has_res && ok[e]) rv[e] = res[(int64_t)(p.res_mod ? (m % p.res_mod) : m) * p.ldres + n];
+                if (has_mask && ok[e]) mv[e] = mask[(int64_t)m * ldmask + n];
+            }
+            // phase C: combine and store
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (ok[e]) {
                     float v = acc[i][j][e] * alpha;
                     v = scale ? v * sc + bi : v + bi;
-                    if (res) {
-                        const int rm = p.res_mod ? (m % p.res_mod) : m;
-                        v += res[(int64_t)rm * p.ldres + n];
-                    }
-                    if (mask && !(mask[(int64_t)m * ldmask + n] > 0.f)) v = 0.f;
+                    v += rv[e];
+                    if (!(mv[e] > 0.f)) v = 0.f;
                     if (p.relu) v = fmaxf(v, 0.f);
-                    const int64_t orow = p.rowmap ? p.rowmap[m] : m;
-                    if (splitk > 1) atomicAdd(&C[orow * p.ldc + n], v);
-                    else C[orow * p.ldc + n] = v;
-                    if (C2) C2[orow * p.ldc + n] = v * sc2;
+                    const int64_t o = (int64_t)orow[e] * p.ldc + n;
+                    if (splitk > 1) atomicAdd(&C[o], v);
+                    else C[o] = v;
+                    if (C2) C2[o] = v * sc2;
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);      // keep the next tile's loads from being hoisted (register pressure)
         }
     }
 }
@@ -369,7 +455,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int tiles_m, 
 template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
 int launch_cfg(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-    constexpr int smem = 2 * stage_f4<BM, BN>() * 16;
+    static const int lds_pad = getenv("ACTMI_GEMM_LDSPAD") ? atoi(getenv("ACTMI_GEMM_LDSPAD")) : 0;   // tuning aid
+    const int smem = 2 * stage_f4<BM, BN>() * 16 + lds_pad;
     auto kern = gemm_f32_kernel<BM, BN, WM, WN, AMODE, BMODE>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -409,6 +496,10 @@ int launch_modes(const GemmArgs& a, hipStream_t st) {
     const double eL = tile_eff(a.M, a.N, nz, 128, 128, 1.00);
     const double eM = tile_eff(a.M, a.N, nz, 128, 64, 0.95);
     const double eS = tile_eff(a.M, a.N, nz, 64, 64, 0.88);
+    static const char* force = getenv("ACTMI_GEMM_CFG");      // tuning aid: L / M / S
+    if (force && force[0] == 'L') return launch_cfg<128, 128, 64, 64, AMODE, BMODE>(a, st);
+    if (force && force[0] == 'M') return launch_cfg<128, 64, 64, 32, AMODE, BMODE>(a, st);
+    if (force && force[0] == 'S') return launch_cfg<64, 64, 32, 32, AMODE, BMODE>(a, st);
     if (eL >= eM && eL >= eS) return launch_cfg<128, 128, 64, 64, AMODE, BMODE>(a, st);
     if (eM >= eS) return launch_cfg<128, 64, 64, 32, AMODE, BMODE>(a, st);
     return launch_cfg<64, 64, 32, 32, AMODE, BMODE>(a, st);
@@ -463,7 +554,8 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t st, std::string* err) {
         if (!a.ta) return fail("wgrad: A (dY) must be given in [m][n] storage (ta=1)");
     } else return fail("bad tb");
     int rc;
-    if (amode == A_N && bmode == B_N) rc = launch_modes<A_N, B_N>(a, st);
+    if (amode == A_N && bmode == B_N && a.A_add) rc = launch_modes<A_NADD, B_N>(a, st);
+    else if (amode == A_N && bmode == B_N) rc = launch_modes<A_N, B_N>(a, st);
     else if (amode == A_CONV && bmode == B_N) rc = launch_modes<A_CONV, B_N>(a, st);
     else if (amode == A_DGRAD && bmode == B_N) rc = launch_modes<A_DGRAD, B_N>(a, st);
     else if (amode == A_N && bmode == B_T) rc = launch_modes<A_N, B_T>(a, st);

@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (metric is quoted at 8)")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer = headline policy-query metric; train = ACT training step (forward+backward+AdamW), fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     args = ap.parse_args()
@@ -70,6 +72,8 @@ def main():
 
     cfg = ACTConfig()                                           # C=4, 480x640, Q=100, D=512, F=3200, 4 enc + 7 dec
     B = args.batch
+    if args.mode == "train":
+        return bench_train(args, cfg, B, dev, rank, world, dist)
     log(f"rank {rank}/{world}: generating weights")
     eng = ACTEngine(cfg, max_batch=B, device=str(dev))
     eng.load_state_dict(W.generate_state_dict(cfg, seed=0))
@@ -144,6 +148,75 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, B, args.cpu_iters)
         print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_train(args, cfg, B, dev, rank, world, dist):
+    """ACT training step (imitate_episodes.py:601-607): zero_grad, forward (CVAE + policy), L1+KL, backward, AdamW."""
+    import torch
+    from actmi import weights as W
+    from actmi import lib as L
+    from actmi.engine import ACTEngine
+    log(f"rank {rank}/{world}: building training engine (batch {B})")
+    eng = ACTEngine(cfg, max_batch=B, device=str(dev), training=True)
+    eng.load_state_dict(W.generate_state_dict(cfg, seed=0))
+    eng.finalize()
+    inp = W.generate_inputs(cfg, B, seed=1234 + rank, with_actions=True)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+
+    def step(i):
+        eng.zero_grad()
+        out = eng.forward_train(t["qpos"], t["image_u8"], t["actions"], t["is_pad"], eps=t["eps"])
+        eng.backward(1.0)
+        eng.adamw_step(1e-5, 1e-5, 1e-4, step=i + 1)
+        return out
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    log("warm-up done")
+    L.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    L.profile_enable(False)
+    prof = [p for p in L.profile_report() if p["ms"] > 0]
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out["loss"]).all()
+    if rank == 0:
+        prof.sort(key=lambda p: -p["ms"])
+        gpu_ms = sum(p["ms"] for p in prof)
+        dom = prof[0]
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        gflop_live = 447.0                                      # SURVEY §8(d): fwd 149 incl. CVAE + bwd ~2x, per sample
+        value = world * B * args.steps / elapsed
+        print(json.dumps({
+            "metric": "ACT training samples/sec (fwd+bwd+AdamW, 4x480x640 cams, chunk=100)", "value": value,
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ACT training step, per-GPU batch {B}, 4 cams 480x640, hidden 512, ff 3200, dropout 0",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"replicas x{world}"},
+            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "avg_launch_us": dom["ms"] * 1e3 / dom["count"]},
+            "whole_step": {"gflop_per_sample_live": gflop_live, "achieved_tflops_live": value / world * gflop_live / 1e3,
+                           "frac_of_fp32_matrix_peak": value / world * gflop_live / 1e3 / PEAK_FP32_MATRIX_TFLOPS,
+                           "gpu_kernel_ms_per_step": gpu_ms / args.steps},
+            "kernels": [{"name": p["name"], "launches_per_step": p["count"] / args.steps, "avg_us": p["ms"] * 1e3 / p["count"],
+                         "share": p["ms"] / gpu_ms, "tflops": (p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["flops"] else None}
+                        for p in prof[:16]],
+        }))
     if world > 1:
         dist.destroy_process_group()
 
