@@ -53,7 +53,7 @@ class AttnDesc(C.Structure):
         ("O", C.c_void_p), ("o_bs", C.c_int64), ("o_rs", C.c_int64),
         ("kpm", C.c_void_p), ("kpm_bs", C.c_int64), ("lse", C.c_void_p),
         ("B", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("HD", C.c_int32),
-        ("scale", C.c_float),
+        ("scale", C.c_float), ("ws", C.c_void_p), ("ws_floats", C.c_int64),
     ]
 
 

@@ -60,7 +60,7 @@ def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1
     return out
 
 
-def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False):
+def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False, split=True):
     """q [B,Nq,D] (or [Nq,D] when q_shared), k/v [B,Nk,D] (views with row stride allowed); returns [B,Nq,D]."""
     lib = L.load()
     B, Nk, D = k.shape
@@ -76,6 +76,9 @@ def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False):
     if kpm is not None:
         d.kpm, d.kpm_bs = kpm.data_ptr(), kpm.stride(0)
     d.lse = lse.data_ptr() if lse is not None else None
+    if split:                                   # workspace for the split-KV path (used when the grid is small)
+        ws = torch.empty(8 * B * Nq * (D + 2 * nheads), dtype=torch.float32, device=k.device)
+        d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
     d.B, d.H, d.Nq, d.Nk, d.HD = B, nheads, Nq, Nk, hd
     d.scale = 1.0 / (hd ** 0.5)
     L.check(lib.actmi_op_attention(C.byref(d), L.current_stream_ptr()), None, "op_attention")

@@ -19,7 +19,7 @@ namespace {
 constexpr int KT = 64;   // keys per LDS tile
 
 template <int HD>
-__global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p, int nsplit, int chunk) {
     constexpr int HH = HD / 2;            // k-steps of the QK^T product per lane half
     constexpr int DT = (HD + 31) / 32;    // 32-wide output tiles along d
     constexpr int VD = DT * 32;
@@ -30,16 +30,21 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int q = blockIdx.x * 128 + wave * 32 + li;
+    const int split = blockIdx.x % nsplit;
+    const int q = (blockIdx.x / nsplit) * 128 + wave * 32 + li;
+    const int k_begin = split * chunk;
+    const int k_end = (k_begin + chunk < p.Nk) ? k_begin + chunk : p.Nk;      // this block's key range
     const bool qok = q < p.Nq;
 
+    // scores are kept in the base-2 domain: s' = s * log2(e), p = 2^(s' - m'), so the exponential is one v_exp_f32
+    const float qscale = p.scale * 1.4426950408889634f;
     const float* Qp = p.Q + (int64_t)b * p.q_bs + (int64_t)(qok ? q : 0) * p.q_rs + h * HD + lh * HH;
     float qreg[HH];
 #pragma unroll
     for (int s = 0; s < HH; s += 4) {
         f32x4 v = *reinterpret_cast<const f32x4*>(Qp + s);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) qreg[s + j] = qok ? v[j] * p.scale : 0.f;
+        for (int j = 0; j < 4; ++j) qreg[s + j] = qok ? v[j] * qscale : 0.f;
     }
     const float* Kb = p.K + (int64_t)b * p.k_bs + h * HD;
     const float* Vb = p.V + (int64_t)b * p.v_bs + h * HD;
@@ -58,25 +63,50 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p) {
         __syncthreads();
     }
 
-    for (int kt0 = 0; kt0 < p.Nk; kt0 += KT) {
-        // ---- stage K and V tiles (float4 along d), zero beyond Nk
-        constexpr int C4 = HD / 4;
-        for (int e = t; e < KT * C4; e += 256) {
+    __shared__ uint8_t s_dead[KT];
+    // software pipeline: the K/V rows of tile t+1 are fetched into registers while tile t is being consumed
+    constexpr int C4 = HD / 4;
+    constexpr int NLD = (KT * C4 + 255) / 256;
+    f32x4 pk[NLD], pv[NLD];
+    auto fetch = [&](int kt0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = t + 256 * i;
             const int kr = e / C4, c = e - kr * C4;
             const int key = kt0 + kr;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (key < p.Nk) {
-                kv = *reinterpret_cast<const f32x4*>(Kb + (int64_t)key * p.k_rs + c * 4);
-                vv = *reinterpret_cast<const f32x4*>(Vb + (int64_t)key * p.v_rs + c * 4);
+            const bool ok = e < KT * C4 && key < k_end;
+            const int64_t koff = ok ? (int64_t)key * p.k_rs + c * 4 : 0;
+            const int64_t voff = ok ? (int64_t)key * p.v_rs + c * 4 : 0;
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(Kb + koff);
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(Vb + voff);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            pk[i] = ok ? kv : z;
+            pv[i] = ok ? vv : z;
+        }
+    };
+    fetch(k_begin);
+    for (int kt0 = k_begin; kt0 < k_end; kt0 += KT) {
+        // ---- stage the prefetched tile
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = t + 256 * i;
+            if (e < KT * C4) {
+                const int kr = e / C4, c = e - kr * C4;
+                *reinterpret_cast<f32x4*>(&s_k[kr * KS + c * 4]) = pk[i];
+                *reinterpret_cast<f32x4*>(&s_v[kr * VD + c * 4]) = pv[i];
             }
-            *reinterpret_cast<f32x4*>(&s_k[kr * KS + c * 4]) = kv;
-            *reinterpret_cast<f32x4*>(&s_v[kr * VD + c * 4]) = vv;
+        }
+        const bool ragged = kt0 + KT > k_end || kpm != nullptr;    // block-uniform: masking only where needed
+        if (ragged && t < KT) {
+            const int key = kt0 + t;
+            s_dead[t] = (key >= k_end) || (kpm && kpm[key] != 0);
         }
         __syncthreads();
+        if (kt0 + KT < k_end) fetch(kt0 + KT);
 #pragma unroll
         for (int sub = 0; sub < KT / 32; ++sub) {
             const int kb = kt0 + sub * 32;
-            if (kb < p.Nk) {
+            if (kb < k_end) {
                 f32x16 S;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) S[e] = 0.f;
@@ -88,23 +118,22 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p) {
                     for (int j = 0; j < 4; ++j)
                         S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[j], qreg[s + j], S, 0, 0, 0);
                 }
-                float mt = -INFINITY;
+                if (ragged) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = kb + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    bool dead = key >= p.Nk;
-                    if (kpm && !dead) dead = kpm[key] != 0;
-                    if (dead) S[e] = -INFINITY;
-                    mt = fmaxf(mt, S[e]);
+                    for (int e = 0; e < 16; ++e)
+                        if (s_dead[sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh]) S[e] = -INFINITY;
                 }
+                float mt = S[0];
+#pragma unroll
+                for (int e = 1; e < 16; ++e) mt = fmaxf(mt, S[e]);
                 mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
                 const float m_new = fmaxf(m_run, mt);
                 const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-                const float alpha = expf(m_run - m_safe);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
                 float rs = 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    S[e] = expf(S[e] - m_safe);
+                    S[e] = __builtin_amdgcn_exp2f(S[e] - m_safe);
                     rs += S[e];
                 }
                 rs += __shfl_xor(rs, 32, 64);
@@ -128,20 +157,66 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p) {
         __syncthreads();
     }
     if (qok) {
-        const float inv = 1.f / l_run;
-        float* Op = p.O + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + h * HD;
+        if (nsplit == 1) {
+            const float inv = 1.f / l_run;
+            float* Op = p.O + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + h * HD;
 #pragma unroll
-        for (int d = 0; d < DT; ++d)
+            for (int d = 0; d < DT; ++d)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = d * 32 + 8 * g + 4 * lh;
-                if (d0 < HD) {
-                    f32x4 o = {O[d][4 * g] * inv, O[d][4 * g + 1] * inv, O[d][4 * g + 2] * inv, O[d][4 * g + 3] * inv};
-                    *reinterpret_cast<f32x4*>(Op + d0) = o;
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = d * 32 + 8 * g + 4 * lh;
+                    if (d0 < HD) {
+                        f32x4 o = {O[d][4 * g] * inv, O[d][4 * g + 1] * inv, O[d][4 * g + 2] * inv, O[d][4 * g + 3] * inv};
+                        *reinterpret_cast<f32x4*>(Op + d0) = o;
+                    }
                 }
-            }
-        if (p.lse && lh == 0) p.lse[((int64_t)b * p.H + h) * p.Nq + q] = m_run + logf(l_run);
+            if (p.lse && lh == 0) p.lse[((int64_t)b * p.H + h) * p.Nq + q] = m_run * 0.6931471805599453f + logf(l_run);
+        } else {
+            // partial result of this key range: un-normalised O plus (running max, running sum)
+            const int64_t row = (((int64_t)split * p.B + b) * p.H + h) * p.Nq + q;
+            float* Op = p.ws + row * HD;
+            float* ml = p.ws + (int64_t)nsplit * p.B * p.H * p.Nq * HD + row * 2;
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = d * 32 + 8 * g + 4 * lh;
+                    if (d0 < HD) {
+                        f32x4 o = {O[d][4 * g], O[d][4 * g + 1], O[d][4 * g + 2], O[d][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(Op + d0) = o;
+                    }
+                }
+            if (lh == 0) { ml[0] = m_run; ml[1] = l_run; }
+        }
     }
+}
+
+// merge the nsplit partial results: m = max m_s, L = sum l_s 2^(m_s - m), O = sum O_s 2^(m_s - m) / L
+__global__ void attn_combine_kernel(AttnArgs p, int nsplit, int HD) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // over (b, h, q, d4)
+    const int D4 = HD / 4;
+    const int64_t total = (int64_t)p.B * p.H * p.Nq * D4;
+    if (idx >= total) return;
+    const int d4 = (int)(idx % D4);
+    const int64_t bhq = idx / D4;
+    const int q = (int)(bhq % p.Nq);
+    const int h = (int)((bhq / p.Nq) % p.H);
+    const int b = (int)(bhq / ((int64_t)p.Nq * p.H));
+    const int64_t per = (int64_t)p.B * p.H * p.Nq;
+    const float* mlb = p.ws + (int64_t)nsplit * per * HD;
+    float m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, mlb[(s * per + bhq) * 2]);
+    const float msafe = (m == -INFINITY) ? 0.f : m;
+    float L = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) {
+        const float w = __builtin_amdgcn_exp2f(mlb[(s * per + bhq) * 2] - msafe);
+        L += mlb[(s * per + bhq) * 2 + 1] * w;
+        acc += *reinterpret_cast<const f32x4*>(p.ws + (s * per + bhq) * HD + d4 * 4) * w;
+    }
+    const float inv = 1.f / L;
+    *reinterpret_cast<f32x4*>(p.O + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + h * HD + d4 * 4) = acc * inv;
+    if (p.lse && d4 == 0) p.lse[bhq] = msafe * 0.6931471805599453f + logf(L);
 }
 
 }  // namespace
@@ -155,7 +230,18 @@ int launch_attention(const AttnArgs& a, hipStream_t st, std::string* err) {
         return fail("strides must be multiples of 4 floats");
     if (((uintptr_t)a.Q & 15) || ((uintptr_t)a.K & 15) || ((uintptr_t)a.V & 15) || ((uintptr_t)a.O & 15))
         return fail("pointers must be 16-byte aligned");
-    dim3 grid((a.Nq + 127) / 128, a.H, a.B);
+    const int qblocks = (a.Nq + 127) / 128;
+    const int tiles = (a.Nk + KT - 1) / KT;
+    int nsplit = 1;
+    if (a.ws) {
+        const long blocks = (long)qblocks * a.H * a.B;
+        nsplit = (int)((1024 + blocks - 1) / blocks);
+        if (nsplit > 8) nsplit = 8;
+        if (nsplit > tiles / 2) nsplit = tiles / 2 > 0 ? tiles / 2 : 1;
+        while (nsplit > 1 && (int64_t)nsplit * a.B * a.Nq * ((int64_t)a.H * a.HD + 2 * a.H) > a.ws_floats) --nsplit;
+    }
+    const int chunk = ((tiles + nsplit - 1) / nsplit) * KT;
+    dim3 grid(qblocks * nsplit, a.H, a.B);
     if (prof_enabled()) {
         char nm[48];
         snprintf(nm, sizeof(nm), "attn_f32_kernel<%d>", a.HD);
@@ -163,10 +249,14 @@ int launch_attention(const AttnArgs& a, hipStream_t st, std::string* err) {
                    4.0 * a.B * a.H * a.HD * (2.0 * a.Nq + 2.0 * a.Nk), st);
     }
     switch (a.HD) {
-        case 64: hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(256), 0, st, a); break;
-        case 32: hipLaunchKernelGGL(attn_f32_kernel<32>, grid, dim3(256), 0, st, a); break;
-        case 16: hipLaunchKernelGGL(attn_f32_kernel<16>, grid, dim3(256), 0, st, a); break;
+        case 64: hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(256), 0, st, a, nsplit, chunk); break;
+        case 32: hipLaunchKernelGGL(attn_f32_kernel<32>, grid, dim3(256), 0, st, a, nsplit, chunk); break;
+        case 16: hipLaunchKernelGGL(attn_f32_kernel<16>, grid, dim3(256), 0, st, a, nsplit, chunk); break;
         default: return fail("head_dim must be 16, 32 or 64");
+    }
+    if (nsplit > 1) {
+        const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.HD / 4);
+        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, nsplit, a.HD);
     }
     prof_end(st);
     hipError_t e = hipGetLastError();

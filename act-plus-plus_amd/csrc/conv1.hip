@@ -23,11 +23,16 @@ constexpr int PROWS = 8;                   // 7 real rows + 1 zero row for the K
 
 __host__ __device__ constexpr int koff(int k) { return (k / 21) * PSTRIDE + (k % 21); }
 
+// number of per-thread staging registers: u8 rows are fetched as 4-byte words (7 rows x 101 words), f32 as scalars
+template <int FMT> struct StageN { static constexpr int value = (FMT == 0) ? 3 : 11; };
+
 template <int FMT>
 __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args p, int tiles_per_row, int tiles_per_cam) {
-    __shared__ __attribute__((aligned(16))) float s_w[64 * WSTRIDE];
-    __shared__ __attribute__((aligned(16))) float s_patch[PROWS * PSTRIDE];
-    __shared__ float s_lut[3 * 256];
+    // one dynamic LDS block (66.8 KB > the 64 KB static limit): weights | two patch buffers | LUT, 16-byte aligned carves
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* s_w = reinterpret_cast<float*>(smem_raw);
+    float (*s_patch)[PROWS * PSTRIDE] = reinterpret_cast<float (*)[PROWS * PSTRIDE]>(s_w + 64 * WSTRIDE);
+    float* s_lut = &s_patch[0][0] + 2 * PROWS * PSTRIDE;
     const int cam = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args p, int tiles_per_r
         s_w[n * WSTRIDE + k] = (n < p.Cout) ? wg[n * KPAD + k] : 0.f;
     }
     for (int e = t; e < 3 * 256; e += 256) s_lut[e] = (FMT == 0) ? p.lut[e] : 0.f;
-    for (int e = t; e < PROWS * PSTRIDE; e += 256) s_patch[e] = 0.f;
+    for (int e = t; e < 2 * PROWS * PSTRIDE; e += 256) (&s_patch[0][0])[e] = 0.f;
     const float mean[3] = {0.485f, 0.456f, 0.406f};
     const float stdv[3] = {0.229f, 0.224f, 0.225f};
     __syncthreads();
@@ -49,43 +54,126 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args p, int tiles_per_r
     const int n = ntile * 32 + li;
     const float sc = (n < p.Cout) ? p.scale[cam * p.Cout + n] : 0.f;
     const float bi = (n < p.Cout) ? p.bias[cam * p.Cout + n] : 0.f;
-    const float* a_base = s_patch + (mtile * 32 + li) * 6;
     const float* b_base = s_w + n * WSTRIDE + lh;
 
-    for (int tile = blockIdx.x; tile < tiles_per_cam; tile += gridDim.x) {
-        const int b = tile / (p.Ho * tiles_per_row);
+    // ---- staging of one tile's 7 x 133 x 3 patch, split in two phases so that the global loads of tile i+1 fly while the
+    //      MFMAs of tile i run: fetch() issues the loads into registers, commit() normalises and writes LDS.
+    constexpr int NS = StageN<FMT>::value;
+    uint32_t sreg[NS];
+    auto tile_coords = [&](int tile, int& b, int& ho, int& wo0) {
+        b = tile / (p.Ho * tiles_per_row);
         const int rem = tile - b * (p.Ho * tiles_per_row);
-        const int ho = rem / tiles_per_row;
-        const int wo0 = (rem - ho * tiles_per_row) * TILE_P;
-        const int64_t img = (int64_t)b * p.C + cam;      // input image index ([B][C] layout of the caller)
-        const int64_t oimg = (int64_t)cam * p.B + b;     // output is camera-major: each camera is one GEMM group
-        // ---- stage the patch (7 rows x 133 cols x 3 ch), zero outside the image
+        ho = rem / tiles_per_row;
+        wo0 = (rem - ho * tiles_per_row) * TILE_P;
+    };
+    auto fetch = [&](int tile) {
+        int b, ho, wo0;
+        tile_coords(tile, b, ho, wo0);
+        const int64_t img = (int64_t)b * p.C + cam;       // input image index ([B][C] layout of the caller)
         const int hi0 = 2 * ho - 3, wi0 = 2 * wo0 - 3;
         if (FMT == 0) {
-            const uint8_t* src = reinterpret_cast<const uint8_t*>(p.image) + img * p.H * p.W * 3;
-            for (int e = t; e < 7 * PCOLS * 3; e += 256) {
-                const int r = e / (PCOLS * 3), x = e - r * (PCOLS * 3);
-                const int pc = x / 3, c = x - pc * 3;
-                const int hi = hi0 + r, wi = wi0 + pc;
-                float v = 0.f;
-                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                    v = s_lut[c * 256 + src[((int64_t)hi * p.W + wi) * 3 + c]];
-                s_patch[r * PSTRIDE + x] = v;
+            // row r of the patch = 399 consecutive bytes starting at byte (hi*W + wi0)*3 of the image; fetched as
+            // 101 aligned 4-byte words (clamped into the image; out-of-image bytes are discarded in commit())
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(p.image) + img * (int64_t)p.H * p.W * 3;
+            const int64_t img_bytes = (int64_t)p.H * p.W * 3;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int e = t + 256 * i;
+                const int r = e / 101, j = e - r * 101;
+                const int hi = hi0 + r;
+                uint32_t v = 0;
+                if (r < 7 && (unsigned)hi < (unsigned)p.H) {
+                    const int64_t a0 = ((int64_t)hi * p.W + wi0) * 3;          // may be negative / past the row: clamp below
+                    int64_t wa = ((a0 >> 2) + j) << 2;                          // aligned word address (floor for negatives)
+                    if (wa < 0) wa = 0;
+                    if (wa > img_bytes - 4) wa = (img_bytes - 4) & ~int64_t(3);
+                    v = *reinterpret_cast<const uint32_t*>(src + wa);
+                }
+                sreg[i] = v;
             }
         } else {
-            const float* src = reinterpret_cast<const float*>(p.image) + img * 3 * p.H * p.W;
-            for (int e = t; e < 7 * 3 * PCOLS; e += 256) {
+            const float* src = reinterpret_cast<const float*>(p.image) + img * 3 * (int64_t)p.H * p.W;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int e = t + 256 * i;
+                const int rc = e / PCOLS, pc = e - rc * PCOLS;
+                const int r = rc / 3, c = rc - r * 3;
+                const int hi = hi0 + r, wi = wi0 + pc;
+                float v = 0.f;
+                if (e < 7 * 3 * PCOLS && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                    v = src[((int64_t)c * p.H + hi) * p.W + wi];
+                sreg[i] = __float_as_uint(v);
+            }
+        }
+    };
+    auto commit = [&](int tile, float* patch) {
+        int b, ho, wo0;
+        tile_coords(tile, b, ho, wo0);
+        const int hi0 = 2 * ho - 3, wi0 = 2 * wo0 - 3;
+        if (FMT == 0) {
+            const int64_t img_bytes = (int64_t)p.H * p.W * 3;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int e = t + 256 * i;
+                const int r = e / 101, j = e - r * 101;
+                const int hi = hi0 + r;
+                if (r >= 7) continue;
+                const bool row_ok = (unsigned)hi < (unsigned)p.H;
+                const int64_t a0 = ((int64_t)hi * p.W + wi0) * 3;
+                int64_t wa = ((a0 >> 2) + j) << 2;
+                const int64_t wa_req = wa;
+                if (wa < 0) wa = 0;
+                if (wa > img_bytes - 4) wa = (img_bytes - 4) & ~int64_t(3);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t ba = wa_req + k;                 // byte address this slot stands for
+                    const int x = (int)(ba - a0);                  // position inside the 399-byte patch row
+                    if (x < 0 || x >= PCOLS * 3) continue;
+                    const int pc = x / 3, c = x - pc * 3;
+                    const int wi = wi0 + pc;
+                    float v = 0.f;
+                    // the word was clamped only when it lies (partly) outside the image: such bytes are padding anyway
+                    if (row_ok && (unsigned)wi < (unsigned)p.W && wa == wa_req)
+                        v = s_lut[c * 256 + ((sreg[i] >> (8 * k)) & 0xFF)];
+                    else if (row_ok && (unsigned)wi < (unsigned)p.W) {
+                        const int64_t sh = ba - wa;                // clamped word still contains this byte if 0 <= sh < 4
+                        if (sh >= 0 && sh < 4) v = s_lut[c * 256 + ((sreg[i] >> (8 * sh)) & 0xFF)];
+                    }
+                    patch[r * PSTRIDE + x] = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int e = t + 256 * i;
+                if (e >= 7 * 3 * PCOLS) continue;
                 const int rc = e / PCOLS, pc = e - rc * PCOLS;
                 const int r = rc / 3, c = rc - r * 3;
                 const int hi = hi0 + r, wi = wi0 + pc;
                 float v = 0.f;
                 if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                    v = (src[((int64_t)c * p.H + hi) * p.W + wi] - mean[c]) / stdv[c];
-                s_patch[r * PSTRIDE + pc * 3 + c] = v;
+                    v = (__uint_as_float(sreg[i]) - mean[c]) / stdv[c];
+                patch[r * PSTRIDE + pc * 3 + c] = v;
             }
         }
-        __syncthreads();
+    };
+
+    int tile = blockIdx.x;
+    if (tile < tiles_per_cam) {
+        fetch(tile);
+        commit(tile, s_patch[0]);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (; tile < tiles_per_cam; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        const bool has_next = next < tiles_per_cam;
+        if (has_next) fetch(next);
+        int b, ho, wo0;
+        tile_coords(tile, b, ho, wo0);
+        const int64_t oimg = (int64_t)cam * p.B + b;     // output is camera-major: each camera is one GEMM group
         if (active) {
+            const float* a_base = s_patch[cur] + (mtile * 32 + li) * 6;
             f32x16 acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -105,7 +193,9 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args p, int tiles_per_r
                 }
             }
         }
+        if (has_next) commit(next, s_patch[cur ^ 1]);     // the other buffer was last read one iteration ago
         __syncthreads();
+        cur ^= 1;
     }
 }
 
@@ -123,8 +213,18 @@ int launch_conv1(const Conv1Args& a, hipStream_t st, std::string* err) {
     dim3 grid(gx, a.C);
     prof_begin(a.fmt == 0 ? "conv1_kernel<0>" : "conv1_kernel<1>", 2.0 * a.B * a.C * a.Ho * a.Wo * a.Cout * 147.0,
                (double)a.B * a.C * ((double)a.H * a.W * 3 * (a.fmt == 0 ? 1 : 4) + 4.0 * a.Ho * a.Wo * a.Cout), st);
-    if (a.fmt == 0) hipLaunchKernelGGL(conv1_kernel<0>, grid, dim3(256), 0, st, a, tiles_per_row, tiles_per_cam);
-    else hipLaunchKernelGGL(conv1_kernel<1>, grid, dim3(256), 0, st, a, tiles_per_row, tiles_per_cam);
+    constexpr int smem = (64 * WSTRIDE + 2 * PROWS * PSTRIDE + 3 * 256) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+            if (err) *err = "conv1: cannot raise the dynamic LDS limit";
+            return -3;
+        }
+        attr_set = true;
+    }
+    if (a.fmt == 0) hipLaunchKernelGGL(conv1_kernel<0>, grid, dim3(256), smem, st, a, tiles_per_row, tiles_per_cam);
+    else hipLaunchKernelGGL(conv1_kernel<1>, grid, dim3(256), smem, st, a, tiles_per_row, tiles_per_cam);
     prof_end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (err) *err = std::string("conv1 launch: ") + hipGetErrorString(e); return -3; }

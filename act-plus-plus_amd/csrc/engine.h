@@ -84,6 +84,8 @@ struct actmi_ctx {
     float *act1 = nullptr, *buf[3] = {nullptr, nullptr, nullptr};
     float *X = nullptr, *X1 = nullptr, *Y = nullptr, *ATT = nullptr, *QKV = nullptr, *Hb = nullptr;
     float *dO = nullptr, *dY = nullptr, *dT2 = nullptr, *dH = nullptr, *hs = nullptr;
+    float* attn_ws = nullptr;          // split-KV partials (attn.hip)
+    int64_t attn_ws_floats = 0;
     std::map<std::string, DbgView> dbg;
     std::string stop_stage;   // debug: return from the forward right after this stage
     TrainState* train = nullptr;

@@ -5,6 +5,7 @@
 // so the whole forward can be captured in a hipGraph by the caller.
 #include "engine.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -298,6 +299,11 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
     if ((rc = dev_alloc(ctx, &ctx->dT2, BQ * D))) return fail(rc);
     if ((rc = dev_alloc(ctx, &ctx->dH, BQ * F))) return fail(rc);
     if ((rc = dev_alloc(ctx, &ctx->hs, BQ * D))) return fail(rc);
+    {
+        const int64_t rows = std::max<int64_t>((int64_t)8 * B * Q, (int64_t)2 * B * N);
+        ctx->attn_ws_floats = rows * (D + 2 * g.nheads);
+        if ((rc = dev_alloc(ctx, &ctx->attn_ws, ctx->attn_ws_floats))) return fail(rc);
+    }
     ctx->finalized = false;
     if (g.enable_training && (rc = train_create(ctx))) return fail(rc);
     *out = ctx;
@@ -484,6 +490,7 @@ int engine_encoder_layer(actmi_ctx* ctx, const EncW& w, float* x, const float* p
     at.O = ctx->ATT; at.o_bs = (int64_t)n * D; at.o_rs = D;
     at.kpm = kpm; at.kpm_bs = n;
     at.B = B; at.H = g.nheads; at.Nq = n; at.Nk = n; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
+    at.ws = ctx->attn_ws; at.ws_floats = ctx->attn_ws_floats;
     CHK(launch_attention(at, st, &ctx->err));
     GemmArgs op = linear_args(ctx->ATT, D, M, D, w.attn.out_w, D, w.attn.out_b, ctx->Y, D);
     op.res = x; op.ldres = D;
@@ -515,6 +522,7 @@ int engine_decoder_infer(actmi_ctx* ctx, int B, float* a_hat, hipStream_t st) {
     at.V = KV + D; at.v_bs = at.k_bs; at.v_rs = 2 * D;
     at.O = ctx->dO; at.o_bs = (int64_t)Q * D; at.o_rs = D;
     at.B = B; at.H = g.nheads; at.Nq = Q; at.Nk = N; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
+    at.ws = ctx->attn_ws; at.ws_floats = ctx->attn_ws_floats;
     CHK(launch_attention(at, st, &ctx->err));
     const int M = B * Q;
     GemmArgs op = linear_args(ctx->dO, D, M, D, d.cross.out_w, D, d.cross.out_b, ctx->dY, D);

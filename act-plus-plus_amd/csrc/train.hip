@@ -168,6 +168,7 @@ int enc_fwd(actmi_ctx* ctx, const EncW& w, EncSave& s, float* out, const float* 
     at.O = s.ATT; at.o_bs = (int64_t)n * D; at.o_rs = D;
     at.kpm = kpm; at.kpm_bs = n; at.lse = s.lse;
     at.B = B; at.H = g.nheads; at.Nq = n; at.Nk = n; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
+    at.ws = ctx->attn_ws; at.ws_floats = ctx->attn_ws_floats;
     CHK(launch_attention(at, st, &ctx->err));
     CHK(lin_fwd(ctx, s.ATT, D, M, D, w.attn.out_w, D, w.attn.out_b, s.Y1, D, s.x_in, 0, st));
     CHK(launch_layernorm(s.Y1, nullptr, 0, w.n1w, w.n1b, nullptr, nullptr, s.X1, M, D, 1e-5f, st, &ctx->err));
@@ -483,6 +484,7 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
         at.V = T.KV + D; at.v_bs = at.k_bs; at.v_rs = 2 * D;
         at.O = T.Oc; at.o_bs = (int64_t)Q * D; at.o_rs = D; at.lse = T.lse_c;
         at.B = B; at.H = g.nheads; at.Nq = Q; at.Nk = N; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
+        at.ws = ctx->attn_ws; at.ws_floats = ctx->attn_ws_floats;
         CHK(launch_attention(at, st, &ctx->err));
     }
     const int M = B * Q;

@@ -109,6 +109,11 @@ typedef struct actmi_attn_desc {
     float* lse;
     int32_t B, H, Nq, Nk, HD;
     float scale;
+    /* optional split-KV workspace: when the (query block x head x batch) grid is too small to fill 256 CUs the key range
+     * is split over `nsplit` blocks whose partial (max, sum, O) are merged by a second kernel.  ws_floats >=
+     * nsplit * B * Nq * (H*HD + 2*H); ws = NULL disables splitting. */
+    float* ws;
+    int64_t ws_floats;
 } actmi_attn_desc;
 
 int actmi_version(void);
