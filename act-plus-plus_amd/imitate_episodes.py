@@ -92,7 +92,7 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
 
     if policy is None:
-        policy = make_policy(policy_class, policy_config)
+        policy = make_policy(policy_class, dict(policy_config, training=False))     # inference-only handle: no grad buffers
         ckpt_path = os.path.join(ckpt_dir, ckpt_name)
         if os.path.isfile(ckpt_path):
             loading_status = policy.deserialize(torch.load(ckpt_path, weights_only=True))

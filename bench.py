@@ -127,6 +127,14 @@ def main():
                     "avg_us": p["ms"] * 1e3 / p["count"], "share": p["ms"] / gpu_ms,
                     "tflops": (p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["flops"] else None,
                     "gbps": p["bytes"] / (p["ms"] * 1e-3) / 1e9} for p in prof]
+        # HBM traffic per launch of the dominant kernel: measured in separate rocprofv3 --pmc passes (FETCH_SIZE,
+        # WRITE_SIZE; gfx950 correction applied) of this same command and committed under profiles/; null if absent
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            traffic = tj["kernels"][dom["name"]]["traffic_bytes_per_launch"] if B == 8 else None
+        except Exception:
+            traffic = None
         out = {
             "metric": "policy steps/sec (4x480x640 cams, chunk=100, bs=8)",
             "value": value, "unit": "policy steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -136,9 +144,10 @@ def main():
                                    "4 enc + 7 dec layers (layer 0 live), per-GPU batch %d, + temporal ensemble" % B,
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": PEAK_FP32_MATRIX_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
                          "avg_launch_us": dom["ms"] * 1e3 / dom["count"], "launches_per_step": dom["count"] / args.steps,
-                         "flop_per_launch": dom["flops"] / dom["count"]},
+                         "flop_per_launch": dom["flops"] / dom["count"],
+                         "algorithmic_bytes_per_launch": dom["bytes"] / dom["count"]},
             "whole_step": {"gflop_per_sample_live": GFLOP_PER_SAMPLE_LIVE,
                            "achieved_tflops_live": value / world * GFLOP_PER_SAMPLE_LIVE / 1e3,
                            "frac_of_fp32_matrix_peak": value / world * GFLOP_PER_SAMPLE_LIVE / 1e3 / PEAK_FP32_MATRIX_TFLOPS,
