@@ -11,7 +11,7 @@ def _p(t):
 
 
 def gemm(A, W, bias=None, scale=None, res=None, res_mod=0, relu=False, a_add=None, add_mod=0, add_ncols=0, rowmap=None,
-         out=None, out_rows=None):
+         out=None, out_rows=None, drop_p=0.0, drop_seed=0):
     """out[rowmap(m)] = act((A' @ W.T) * scale + bias + res[m % res_mod]); A [M,K], W [N,K] row-major f32 cuda."""
     lib = L.load()
     M, K = A.shape
@@ -31,6 +31,7 @@ def gemm(A, W, bias=None, scale=None, res=None, res_mod=0, relu=False, a_add=Non
     d.C, d.ldc = out.data_ptr(), out.stride(0)
     d.rowmap = rowmap.data_ptr() if rowmap is not None else None
     d.M, d.N, d.K, d.groups = M, N, K, 1
+    d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)
     L.check(lib.actmi_op_gemm(C.byref(d), L.current_stream_ptr()), None, "op_gemm")
     return out
 
@@ -60,7 +61,7 @@ def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1
     return out
 
 
-def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False, split=True):
+def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False, split=True, drop_p=0.0, drop_seed=0):
     """q [B,Nq,D] (or [Nq,D] when q_shared), k/v [B,Nk,D] (views with row stride allowed); returns [B,Nq,D]."""
     lib = L.load()
     B, Nk, D = k.shape
@@ -81,6 +82,7 @@ def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False, split=T
         d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
     d.B, d.H, d.Nq, d.Nk, d.HD = B, nheads, Nq, Nk, hd
     d.scale = 1.0 / (hd ** 0.5)
+    d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)
     L.check(lib.actmi_op_attention(C.byref(d), L.current_stream_ptr()), None, "op_attention")
     return (out, lse) if want_lse else out
 

@@ -12,6 +12,7 @@
 // movement).  The head-dim contraction order is free, so lane-half h takes d = h*HD/2 + s at step s and reads
 // K rows as ds_read_b128 (row stride HD+4 floats: conflict-free); V is read as ds_read_b32 along d.
 #include "common.h"
+#include "dropout.h"
 #include <cstdio>
 
 namespace {
@@ -137,8 +138,17 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p, int nsplit, i
                     rs += S[e];
                 }
                 rs += __shfl_xor(rs, 32, 64);
-                l_run = l_run * alpha + rs;
+                l_run = l_run * alpha + rs;          // the normaliser uses the UN-dropped weights (dropout acts on softmax output)
                 m_run = m_new;
+                if (p.drop_p > 0.f) {
+                    const float ds = 1.f / (1.f - p.drop_p);
+                    const uint64_t rowbase = (((uint64_t)b * p.H + h) * p.Nq + (qok ? q : 0)) * (uint64_t)p.Nk;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = kb + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        S[e] = actmi_keep(p.drop_seed, rowbase + key, p.drop_p) ? S[e] * ds : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int d = 0; d < DT; ++d)
 #pragma unroll

@@ -3,6 +3,7 @@
 // Reference semantics: torch autograd of the modules in transformer.py / detr_vae.py / policy.py:288-320,
 // torch.optim.AdamW as configured at detr/main.py:102-110.
 #include "common.h"
+#include "dropout.h"
 
 namespace {
 
@@ -73,14 +74,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
             }
         }
     }
+    // block-level reduction of the 4 waves' partials through LDS, then ONE atomic per column per block
+    // (4096 waves adding to the same 2*D addresses was 15x slower than the row pass itself)
+    __shared__ float s_part[2][3][64 * 4 * MAXV];
+    const int wv = threadIdx.x >> 6;
+    if (wv > 0) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < D4) {
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D4) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(&dw[c * 4 + e], aw[i][e]);
-                atomicAdd(&db[c * 4 + e], ab[i][e]);
+                for (int e = 0; e < 4; ++e) { s_part[0][wv - 1][c * 4 + e] = aw[i][e]; s_part[1][wv - 1][c * 4 + e] = ab[i][e]; }
+            }
+        }
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = c * 4 + e;
+                    atomicAdd(&dw[k], aw[i][e] + s_part[0][0][k] + s_part[0][1][k] + s_part[0][2][k]);
+                    atomicAdd(&db[k], ab[i][e] + s_part[1][0][k] + s_part[1][1][k] + s_part[1][2][k]);
+                }
             }
         }
     }
@@ -335,14 +354,68 @@ __global__ void relu_bn_bwd_kernel(const float* __restrict__ x, const float* __r
     if (y_scaled) y_scaled[idx] = v * scale[g * C + c];
 }
 
+// dz[i] = keep(seed, i) ? dy[i] / (1-p) : 0   (backward of an epilogue dropout; i = element index of the forward output)
+__global__ void dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dz, uint64_t seed, float p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dz[i] = actmi_keep(seed, (uint64_t)i, p) ? dy[i] * (1.f / (1.f - p)) : 0.f;
+}
+
+// Pd = P * mask / (1-p) written to a second buffer (the dropped weights feed dV = Pd^T dO)
+__global__ void attn_drop_kernel(const float* __restrict__ P, float* __restrict__ Pd, uint64_t seed, float p, int Nk, int ldp,
+                                 int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int k = (int)(idx % ldp);
+    const int64_t gq = idx / ldp;
+    Pd[idx] = (k < Nk && actmi_keep(seed, (uint64_t)gq * Nk + k, p)) ? P[idx] * (1.f / (1.f - p)) : 0.f;
+}
+
+// dS = P * (dPd * mask/(1-p) - delta) * scale, in place of dPd
+__global__ void attn_ds_drop_kernel(const float* __restrict__ P, float* __restrict__ dP, const float* __restrict__ delta,
+                                    float scale, uint64_t seed, float p, int Nk, int ldp, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int k = (int)(idx % ldp);
+    const int64_t gq = idx / ldp;
+    float v = 0.f;
+    if (k < Nk) {
+        const float g = actmi_keep(seed, (uint64_t)gq * Nk + k, p) ? dP[idx] * (1.f / (1.f - p)) : 0.f;
+        v = P[idx] * (g - delta[gq]) * scale;
+    }
+    dP[idx] = v;
+}
+
 }  // namespace
+
+int launch_dropout_bwd(const float* dy, float* dz, uint64_t seed, float p, int64_t n, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, dz, seed, p, n);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_attn_drop(const float* P, float* Pd, uint64_t seed, float p, int G, int Nq, int Nk, int ldp, hipStream_t st) {
+    const int64_t total = (int64_t)G * Nq * ldp;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(attn_drop_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, Pd, seed, p, Nk, ldp, total);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_attn_ds_drop(const float* P, float* dP, const float* delta, float scale, uint64_t seed, float p, int G, int Nq,
+                        int Nk, int ldp, hipStream_t st) {
+    const int64_t total = (int64_t)G * Nq * ldp;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(attn_ds_drop_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, dP, delta, scale, seed, p,
+                       Nk, ldp, total);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 
 int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* dx_add, float* dx, float* dw, float* db,
                   int M, int D, float eps, hipStream_t st) {
     if ((D & 3) || D > 64 * 4 * MAXV) return -2;
     if (M <= 0) return 0;
     int blocks = (M + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 256) blocks = 256;
     prof_begin("ln_bwd_kernel", 0.0, 4.0 * M * D * 3.0, st);
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, x, w, dy, dx_add, dx, dw, db, M, D, eps);
     prof_end(st);

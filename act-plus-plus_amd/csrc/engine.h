@@ -55,6 +55,11 @@ struct TrainState {
           *Y2pre = nullptr, *T2 = nullptr, *Hd = nullptr, *Y3pre = nullptr, *T3 = nullptr, *hs = nullptr, *a_hat = nullptr,
           *actions = nullptr, *losses = nullptr;
     uint8_t* is_pad = nullptr;
+    // general decoder self-attention path (dropout > 0)
+    float drop_p = 0.f;
+    uint64_t drop_seed = 0;
+    float *qkd = nullptr, *sO = nullptr, *lse_s = nullptr, *saB = nullptr, *T1B = nullptr, *dqB = nullptr, *gT1 = nullptr,
+          *dsaB = nullptr, *dqkB = nullptr, *dvB = nullptr, *dqk_d = nullptr, *tmpQD = nullptr;
     // backward scratch
     float *gA = nullptr, *gB = nullptr, *gC = nullptr, *gH = nullptr, *gQKV = nullptr, *Pbuf = nullptr, *dPbuf = nullptr,
           *delta = nullptr, *dXg = nullptr, *tmp2BD = nullptr, *tmpD = nullptr, *dqb = nullptr;

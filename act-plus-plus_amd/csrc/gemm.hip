@@ -18,6 +18,7 @@
 // operands stored out-contiguous ([contraction][out]) are staged as 4x4 micro-tiles transposed in registers.
 // Planes are padded by one float4 so that the lanes writing one row's chunks hit different bank groups.
 #include "common.h"
+#include "dropout.h"
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -403,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int tiles_
     float* C2 = p.C2 ? p.C2 + (int64_t)g * p.gC2out : nullptr;
     const float alpha = p.alpha != 0.f ? p.alpha : 1.f;
     const bool has_res = res != nullptr, has_mask = mask != nullptr, has_map = p.rowmap != nullptr;
+    const float drop_scale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wcol0 + j * 32 + li;
@@ -438,10 +440,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int tiles_
                 if (ok[e]) {
                     float v = acc[i][j][e] * alpha;
                     v = scale ? v * sc + bi : v + bi;
+                    const int64_t o = (int64_t)orow[e] * p.ldc + n;
+                    if (p.drop_p > 0.f) {
+                        if (p.relu && !has_res) v = fmaxf(v, 0.f);          // dropout(relu(x)) for the FFN hidden layer
+                        v = actmi_keep(p.drop_seed, (uint64_t)(offC + o), p.drop_p) ? v * drop_scale : 0.f;
+                    }
                     v += rv[e];
                     if (!(mv[e] > 0.f)) v = 0.f;
                     if (p.relu) v = fmaxf(v, 0.f);
-                    const int64_t o = (int64_t)orow[e] * p.ldc + n;
                     if (splitk > 1) atomicAdd(&C[o], v);
                     else C[o] = v;
                     if (C2) C2[o] = v * sc2;

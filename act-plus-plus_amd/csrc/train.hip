@@ -9,6 +9,7 @@
 // a parameter whose .grad is None); the decoder layer-0 self-attention on tgt = 0 reduces to out_proj(b_v) + b_o, so
 // its q/k projections and the v weight receive exactly-zero gradients while b_v, out_proj and norm1 do not.
 #include "engine.h"
+#include "dropout.h"
 
 #include <cmath>
 #include <cstring>
@@ -63,21 +64,27 @@ int pick_splitk(int M, int N, int groups, int K) {
 
 // y[M][N] = x[M][K] W[N][K]^T + b (+res) (relu)
 int lin_fwd(actmi_ctx* ctx, const float* x, int64_t ldx, int M, int K, const float* W, int N, const float* b, float* y,
-            int64_t ldy, const float* res, int relu, hipStream_t st) {
+            int64_t ldy, const float* res, int relu, hipStream_t st, float drop_p = 0.f, uint64_t drop_seed = 0) {
     GemmArgs a = G0();
     a.A = x; a.lda = ldx; a.M = M; a.K = K; a.N = N; a.Bw = W; a.ldb = K; a.bias = b; a.C = y; a.ldc = ldy;
-    a.res = res; a.ldres = ldy; a.relu = relu;
+    a.res = res; a.ldres = ldy; a.relu = relu; a.drop_p = drop_p; a.drop_seed = drop_seed;
     return launch_gemm(a, st, &ctx->err);
 }
 
 // dx[M][K] = dy[M][N] W[N][K] (+res) (masked by mask>0)
 int lin_dgrad(actmi_ctx* ctx, const float* dy, int64_t lddy, int M, int N, const float* W, int K, float* dx, int64_t lddx,
-              const float* res, const float* mask, hipStream_t st) {
+              const float* res, const float* mask, hipStream_t st, float alpha = 1.f) {
     GemmArgs a = G0();
     a.A = dy; a.lda = lddy; a.M = M; a.K = N; a.N = K; a.Bw = W; a.ldb = K; a.tb = 1; a.C = dx; a.ldc = lddx;
-    a.res = res; a.ldres = lddx; a.mask = mask; a.ldmask = lddx;
+    a.res = res; a.ldres = lddx; a.mask = mask; a.ldmask = lddx; a.alpha = alpha;
     return launch_gemm(a, st, &ctx->err);
 }
+
+// dropout sites of one layer: 0 attention weights, 1 after the attention out-projection, 2 FFN hidden, 3 after linear2
+struct Drop {
+    float p; uint64_t seed; uint32_t base;
+    uint64_t s(uint32_t k) const { return actmi_site_seed(seed, base + k); }
+};
 
 // dW[N][K] += dy[M][N]^T x'[M][K],  x' = x + x_add[m % add_mod];  db[N] += colsum(dy)
 int lin_wgrad(actmi_ctx* ctx, const float* dy, int64_t lddy, int M, int N, const float* x, int64_t ldx, int K,
@@ -103,6 +110,7 @@ struct AttnBwd {
     int64_t dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
     const uint8_t* kpm; int64_t kpm_bs;
     int B, H, Nq, Nk, HD;
+    float drop_p; uint64_t drop_seed;
 };
 
 int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
@@ -120,21 +128,27 @@ int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
     s.gA = t.q_bs; s.gA2 = t.HD; s.gB = t.k_bs; s.gB2 = t.HD; s.gC = pg * t.H; s.gC2 = pg;
     CHK(launch_gemm(s, st, &ctx->err));
     CHK(launch_attn_probs(P, t.lse, t.kpm, t.kpm_bs, G, t.H, t.Nq, t.Nk, ldp, st));
+    CHK(launch_attn_delta(t.dO, t.O, T.delta, t.B, t.H, t.Nq, t.HD, st));
+    // dV[key][d] = sum_q Pd[q][key] dO[q][d]   (Pd = dropped weights; staged in the dP buffer before dP overwrites it)
+    const float* Pv = P;
+    if (t.drop_p > 0.f) {
+        CHK(launch_attn_drop(P, dP, t.drop_seed, t.drop_p, G, t.Nq, t.Nk, ldp, st));
+        Pv = dP;
+    }
+    GemmArgs v = G0();
+    v.A = Pv; v.lda = ldp; v.ta = 1; v.M = t.Nk; v.K = t.Nq; v.Bw = t.dO; v.ldb = D; v.tb = 1; v.N = t.HD;
+    v.C = t.dV; v.ldc = t.dv_rs; v.groups = G; v.groups_inner = t.H;
+    v.gA = pg * t.H; v.gA2 = pg; v.gB = (int64_t)t.Nq * D; v.gB2 = t.HD; v.gC = t.dv_bs; v.gC2 = t.HD;
+    CHK(launch_gemm(v, st, &ctx->err));
     // dP = dO V^T
     GemmArgs d = G0();
     d.A = t.dO; d.lda = D; d.M = t.Nq; d.K = t.HD; d.Bw = t.V; d.ldb = t.v_rs; d.N = t.Nk; d.C = dP; d.ldc = ldp;
     d.groups = G; d.groups_inner = t.H;
     d.gA = (int64_t)t.Nq * D; d.gA2 = t.HD; d.gB = t.v_bs; d.gB2 = t.HD; d.gC = pg * t.H; d.gC2 = pg;
     CHK(launch_gemm(d, st, &ctx->err));
-    CHK(launch_attn_delta(t.dO, t.O, T.delta, t.B, t.H, t.Nq, t.HD, st));
-    // dV[key][d] = sum_q P[q][key] dO[q][d]
-    GemmArgs v = G0();
-    v.A = P; v.lda = ldp; v.ta = 1; v.M = t.Nk; v.K = t.Nq; v.Bw = t.dO; v.ldb = D; v.tb = 1; v.N = t.HD;
-    v.C = t.dV; v.ldc = t.dv_rs; v.groups = G; v.groups_inner = t.H;
-    v.gA = pg * t.H; v.gA2 = pg; v.gB = (int64_t)t.Nq * D; v.gB2 = t.HD; v.gC = t.dv_bs; v.gC2 = t.HD;
-    CHK(launch_gemm(v, st, &ctx->err));
-    // dS = P * (dP - delta) * scale   (in place of dP)
-    CHK(launch_attn_ds(P, dP, T.delta, scale, G, t.Nq, t.Nk, ldp, st));
+    // dS = P * (dP - delta) * scale   (in place of dP; with dropout dP = dPd * mask / (1-p))
+    if (t.drop_p > 0.f) CHK(launch_attn_ds_drop(P, dP, T.delta, scale, t.drop_seed, t.drop_p, G, t.Nq, t.Nk, ldp, st));
+    else CHK(launch_attn_ds(P, dP, T.delta, scale, G, t.Nq, t.Nk, ldp, st));
     // dQ[q][d] = sum_key dS[q][key] K[key][d]
     GemmArgs q = G0();
     q.A = dP; q.lda = ldp; q.M = t.Nq; q.K = t.Nk; q.Bw = t.K; q.ldb = t.k_rs; q.tb = 1; q.N = t.HD;
@@ -152,7 +166,7 @@ int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
 
 // ---- one post-norm encoder layer, forward with saved activations (transformer.py:211-224) ------------------------
 int enc_fwd(actmi_ctx* ctx, const EncW& w, EncSave& s, float* out, const float* pos, int B, int n, const uint8_t* kpm,
-            hipStream_t st) {
+            const Drop& dr, hipStream_t st) {
     const actmi_config& g = ctx->cfg;
     const int D = g.hidden_dim, F = g.dim_feedforward, M = B * n, hd = D / g.nheads;
     GemmArgs qkv = G0();
@@ -169,48 +183,55 @@ int enc_fwd(actmi_ctx* ctx, const EncW& w, EncSave& s, float* out, const float* 
     at.kpm = kpm; at.kpm_bs = n; at.lse = s.lse;
     at.B = B; at.H = g.nheads; at.Nq = n; at.Nk = n; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
     at.ws = ctx->attn_ws; at.ws_floats = ctx->attn_ws_floats;
+    at.drop_p = dr.p; at.drop_seed = dr.s(0);
     CHK(launch_attention(at, st, &ctx->err));
-    CHK(lin_fwd(ctx, s.ATT, D, M, D, w.attn.out_w, D, w.attn.out_b, s.Y1, D, s.x_in, 0, st));
+    CHK(lin_fwd(ctx, s.ATT, D, M, D, w.attn.out_w, D, w.attn.out_b, s.Y1, D, s.x_in, 0, st, dr.p, dr.s(1)));
     CHK(launch_layernorm(s.Y1, nullptr, 0, w.n1w, w.n1b, nullptr, nullptr, s.X1, M, D, 1e-5f, st, &ctx->err));
-    CHK(lin_fwd(ctx, s.X1, D, M, D, w.l1w, F, w.l1b, s.Hb, F, nullptr, 1, st));
-    CHK(lin_fwd(ctx, s.Hb, F, M, F, w.l2w, D, w.l2b, s.Y2, D, s.X1, 0, st));
+    CHK(lin_fwd(ctx, s.X1, D, M, D, w.l1w, F, w.l1b, s.Hb, F, nullptr, 1, st, dr.p, dr.s(2)));
+    CHK(lin_fwd(ctx, s.Hb, F, M, F, w.l2w, D, w.l2b, s.Y2, D, s.X1, 0, st, dr.p, dr.s(3)));
     CHK(launch_layernorm(s.Y2, nullptr, 0, w.n2w, w.n2b, nullptr, nullptr, out, M, D, 1e-5f, st, &ctx->err));
     return 0;
 }
 
 // backward of the same layer: dOut -> dIn (dIn may alias T.gB); grads accumulate into the gradient arena
 int enc_bwd(actmi_ctx* ctx, const EncW& w, const EncSave& s, const float* dOut, float* dIn, const float* pos, int B, int n,
-            const uint8_t* kpm, float* dpos2 /* [2][D] additional_pos_embed grad or null */, hipStream_t st) {
+            const uint8_t* kpm, float* dpos2 /* [2][D] additional_pos_embed grad or null */, const Drop& dr, hipStream_t st) {
     TrainState& T = *ctx->train;
     const actmi_config& g = ctx->cfg;
     const int D = g.hidden_dim, F = g.dim_feedforward, M = B * n, hd = D / g.nheads;
     auto Gp = [&](const float* p) { return T.gbase + (p - ctx->pbase); };
     float* gA = T.gA; float* gC = T.gC; float* gH = T.gH; float* gQKV = T.gQKV;
-    float* gB = T.gB;
-    // norm2
+    const bool drop = dr.p > 0.f;
+    const float inv_keep = drop ? 1.f / (1.f - dr.p) : 1.f;
+    // norm2:  Y2 = X1 + drop3(linear2(Hb))
     CHK(launch_ln_bwd(s.Y2, w.n2w, dOut, nullptr, gA, Gp(w.n2w), Gp(w.n2b), M, D, 1e-5f, st));             // gA = dY2
-    // linear2 / relu / linear1
-    CHK(lin_dgrad(ctx, gA, D, M, D, w.l2w, F, gH, F, nullptr, s.Hb, st));                                    // gH = dHpre
-    CHK(lin_wgrad(ctx, gA, D, M, D, s.Hb, F, F, nullptr, 0, Gp(w.l2w), Gp(w.l2b), st));
+    const float* dz2 = gA;
+    if (drop) { CHK(launch_dropout_bwd(gA, gC, dr.s(3), dr.p, (int64_t)M * D, st)); dz2 = gC; }
+    // linear2 / dropout / relu / linear1:  Hb = drop2(relu(linear1(X1))); dropped or negative entries are 0 in Hb
+    CHK(lin_dgrad(ctx, dz2, D, M, D, w.l2w, F, gH, F, nullptr, s.Hb, st, inv_keep));                         // gH = dHpre
+    CHK(lin_wgrad(ctx, dz2, D, M, D, s.Hb, F, F, nullptr, 0, Gp(w.l2w), Gp(w.l2b), st));
     CHK(lin_dgrad(ctx, gH, F, M, F, w.l1w, D, gC, D, gA, nullptr, st));                                      // gC = dX1
     CHK(lin_wgrad(ctx, gH, F, M, F, s.X1, D, D, nullptr, 0, Gp(w.l1w), Gp(w.l1b), st));
-    // norm1
+    // norm1:  Y1 = x_in + drop1(out_proj(ATT))
     CHK(launch_ln_bwd(s.Y1, w.n1w, gC, nullptr, gA, Gp(w.n1w), Gp(w.n1b), M, D, 1e-5f, st));               // gA = dY1
-    // out_proj
-    CHK(lin_dgrad(ctx, gA, D, M, D, w.attn.out_w, D, gC, D, nullptr, nullptr, st));                         // gC = dATT
-    CHK(lin_wgrad(ctx, gA, D, M, D, s.ATT, D, D, nullptr, 0, Gp(w.attn.out_w), Gp(w.attn.out_b), st));
+    const float* dz1 = gA;
+    if (drop) { CHK(launch_dropout_bwd(gA, gC, dr.s(1), dr.p, (int64_t)M * D, st)); dz1 = gC; }
+    float* dATT = gH;                                                                                        // [M][D] view
+    CHK(lin_dgrad(ctx, dz1, D, M, D, w.attn.out_w, D, dATT, D, nullptr, nullptr, st));
+    CHK(lin_wgrad(ctx, dz1, D, M, D, s.ATT, D, D, nullptr, 0, Gp(w.attn.out_w), Gp(w.attn.out_b), st));
     // attention
     AttnBwd t;
     memset(&t, 0, sizeof(t));
     const int64_t bs = (int64_t)n * 3 * D;
-    t.Q = s.QKV; t.K = s.QKV + D; t.V = s.QKV + 2 * D; t.O = s.ATT; t.dO = gC; t.lse = s.lse;
+    t.Q = s.QKV; t.K = s.QKV + D; t.V = s.QKV + 2 * D; t.O = s.ATT; t.dO = dATT; t.lse = s.lse;
     t.q_bs = t.k_bs = t.v_bs = bs; t.q_rs = t.k_rs = t.v_rs = 3 * D;
     t.dQ = gQKV; t.dK = gQKV + D; t.dV = gQKV + 2 * D;
     t.dq_bs = t.dk_bs = t.dv_bs = bs; t.dq_rs = t.dk_rs = t.dv_rs = 3 * D;
     t.kpm = kpm; t.kpm_bs = n; t.B = B; t.H = g.nheads; t.Nq = n; t.Nk = n; t.HD = hd;
+    t.drop_p = dr.p; t.drop_seed = dr.s(0);
     CHK(attn_bwd(ctx, t, st));
     // in_proj: dIn = dQKV W_in + dY1 ; dW rows [0,2D) see x+pos, rows [2D,3D) see x
-    CHK(lin_dgrad(ctx, gQKV, 3 * D, M, 3 * D, w.attn.in_w, D, dIn == gB ? gB : dIn, D, gA, nullptr, st));
+    CHK(lin_dgrad(ctx, gQKV, 3 * D, M, 3 * D, w.attn.in_w, D, dIn, D, gA, nullptr, st));
     CHK(lin_wgrad(ctx, gQKV, 3 * D, M, 2 * D, s.x_in, D, D, pos, n, Gp(w.attn.in_w), nullptr, st));
     CHK(lin_wgrad(ctx, gQKV + 2 * D, 3 * D, M, D, s.x_in, D, D, nullptr, 0, Gp(w.attn.in_w) + (int64_t)2 * D * D, nullptr, st));
     CHK(launch_colsum(gQKV, 3 * D, Gp(w.attn.in_b), M, 3 * D, st));
@@ -341,6 +362,9 @@ int train_create(actmi_ctx* ctx) {
     TA(T.KV, (int64_t)B * N * 2 * D); TA(T.lse_c, (int64_t)B * H * Q); TA(T.Oc, BQ * D); TA(T.Y2pre, BQ * D);
     TA(T.T2, BQ * D); TA(T.Hd, BQ * F); TA(T.Y3pre, BQ * D); TA(T.T3, BQ * D); TA(T.hs, BQ * D);
     TA(T.a_hat, BQ * A); TA(T.actions, BQ * A);
+    TA(T.qkd, (int64_t)Q * 2 * D); TA(T.sO, BQ * D); TA(T.lse_s, (int64_t)B * H * Q); TA(T.saB, BQ * D); TA(T.T1B, BQ * D);
+    TA(T.dqB, BQ * D); TA(T.gT1, BQ * D); TA(T.dsaB, BQ * D); TA(T.dqkB, BQ * 2 * D); TA(T.dvB, BQ * D); TA(T.dqk_d, (int64_t)Q * 2 * D);
+    TA(T.tmpQD, (int64_t)Q * D);
     { float* t; TA(t, (BQ + 3) / 4 + 1); T.is_pad = reinterpret_cast<uint8_t*>(t); }
     TA(T.losses, 4);
     // backward scratch
@@ -369,16 +393,16 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
                   const float* eps, uint64_t dropout_seed, float dropout_p, int B, float* losses, float* a_hat_out,
                   float* mu_out, float* logvar_out, hipStream_t st) {
     ctx->err.clear();
-    (void)dropout_seed;
     if (!ctx->train) { ctx->err = "handle was created without enable_training"; return ACTMI_E_STATE; }
     if (!ctx->finalized) { ctx->err = "forward before finalize"; return ACTMI_E_STATE; }
     if (B < 1 || B > ctx->cfg.max_batch) { ctx->err = "batch exceeds max_batch"; return ACTMI_E_INVALID; }
-    if (dropout_p != 0.f) { ctx->err = "dropout_p != 0 is not supported by this build (train with dropout 0)"; return ACTMI_E_INVALID; }
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) { ctx->err = "dropout_p must be in [0, 1)"; return ACTMI_E_INVALID; }
     TrainState& T = *ctx->train;
     const actmi_config& g = ctx->cfg;
     const int C = g.num_cams, D = g.hidden_dim, F = g.dim_feedforward, Q = g.num_queries, N = ctx->N, w0 = g.base_width,
               L = g.latent_dim, A = g.action_dim, S = g.state_dim, hd = D / g.nheads;
-    T.B = B; T.fmt = fmt;
+    T.B = B; T.fmt = fmt; T.drop_p = dropout_p; T.drop_seed = dropout_seed;
+    const Drop dr_dec{dropout_p, dropout_seed, 200};
     HIPCHK(hipMemcpyAsync(T.actions, actions, (size_t)B * Q * A * 4, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(T.is_pad, is_pad, (size_t)B * Q, hipMemcpyDeviceToDevice, st));
     T.qpos = qpos;
@@ -398,7 +422,7 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
         CHK(launch_gemm(ap, st, &ctx->err));
         for (int l = 0; l < g.enc_layers; ++l) {
             float* out = (l + 1 < g.enc_layers) ? T.cv[l + 1].x_in : T.cv_out;
-            CHK(enc_fwd(ctx, ctx->cvae[l], T.cv[l], out, ctx->P("pos_table"), B, n, T.ckpm, st));
+            CHK(enc_fwd(ctx, ctx->cvae[l], T.cv[l], out, ctx->P("pos_table"), B, n, T.ckpm, Drop{dropout_p, dropout_seed, (uint32_t)(8 * l)}, st));
         }
         CHK(lin_fwd(ctx, T.cv_out, (int64_t)n * D, B, D, ctx->P("latent_proj.weight"), 2 * L, ctx->P("latent_proj.bias"),
                     T.latent_info, 2 * L, nullptr, 0, st));
@@ -458,18 +482,40 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
     // ---- encoder
     for (int l = 0; l < g.enc_layers; ++l) {
         float* out = (l + 1 < g.enc_layers) ? T.en[l + 1].x_in : T.mem;
-        CHK(enc_fwd(ctx, ctx->enc[l], T.en[l], out, ctx->pos_tokens, B, N, nullptr, st));
+        CHK(enc_fwd(ctx, ctx->enc[l], T.en[l], out, ctx->pos_tokens, B, N, nullptr, Drop{dropout_p, dropout_seed, (uint32_t)(100 + 8 * l)}, st));
     }
 
     // ---- decoder layer 0 (transformer.py:274-295 with tgt = 0) + final norm + head
     const DecW& d = ctx->dec[0];
-    CHK(lin_fwd(ctx, d.self_attn.in_b + 2 * D, D, 1, D, d.self_attn.out_w, D, d.self_attn.out_b, T.sa_tmp, D, nullptr, 0, st));
-    CHK(launch_layernorm(T.sa_tmp, nullptr, 0, d.n1w, d.n1b, nullptr, nullptr, T.t1, 1, D, 1e-5f, st, &ctx->err));
-    {
+    const int M = B * Q;
+    const bool gen = dropout_p > 0.f;      // general decoder self-attention path (dropout makes it batch dependent)
+    if (!gen) {
+        // tgt = 0: self-attention output is out_proj(b_v) + b_o for every query
+        CHK(lin_fwd(ctx, d.self_attn.in_b + 2 * D, D, 1, D, d.self_attn.out_w, D, d.self_attn.out_b, T.sa_tmp, D, nullptr, 0, st));
+        CHK(launch_layernorm(T.sa_tmp, nullptr, 0, d.n1w, d.n1b, nullptr, nullptr, T.t1, 1, D, 1e-5f, st, &ctx->err));
         // qin = query_embed + t1 (materialised: it is the x operand of the q weight gradient), q = qin Wq^T + bq
         HIPCHK(hipMemcpyAsync(T.qin, ctx->P("query_embed.weight"), (size_t)Q * D * 4, hipMemcpyDeviceToDevice, st));
         CHK(launch_bcast_add_rows(T.qin, T.t1, Q, D, st));
         CHK(lin_fwd(ctx, T.qin, D, Q, D, d.cross.in_w, D, d.cross.in_b, T.dq, D, nullptr, 0, st));
+    } else {
+        // with dropout the self-attention is no longer constant: weights softmax(q k^T) of q = k = query_pos are dropped per
+        // (batch, head, query, key), the value rows are all b_v, so out[b,i] = b_v * rowsum(dropped weights) per head
+        CHK(lin_fwd(ctx, ctx->P("query_embed.weight"), D, Q, D, d.self_attn.in_w, 2 * D, d.self_attn.in_b, T.qkd, 2 * D, nullptr, 0, st));
+        AttnArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.Q = T.qkd; sa.q_bs = 0; sa.q_rs = 2 * D;
+        sa.K = T.qkd + D; sa.k_bs = 0; sa.k_rs = 2 * D;
+        sa.V = d.self_attn.in_b + 2 * D; sa.v_bs = 0; sa.v_rs = 0;
+        sa.O = T.sO; sa.o_bs = (int64_t)Q * D; sa.o_rs = D; sa.lse = T.lse_s;
+        sa.B = B; sa.H = g.nheads; sa.Nq = Q; sa.Nk = Q; sa.HD = hd; sa.scale = 1.0f / sqrtf((float)hd);
+        sa.drop_p = dropout_p; sa.drop_seed = dr_dec.s(0);
+        CHK(launch_attention(sa, st, &ctx->err));
+        CHK(lin_fwd(ctx, T.sO, D, M, D, d.self_attn.out_w, D, d.self_attn.out_b, T.saB, D, nullptr, 0, st, dropout_p, dr_dec.s(1)));
+        CHK(launch_layernorm(T.saB, nullptr, 0, d.n1w, d.n1b, nullptr, nullptr, T.T1B, M, D, 1e-5f, st, &ctx->err));
+        GemmArgs qg = G0();
+        qg.A = T.T1B; qg.lda = D; qg.M = M; qg.K = D; qg.Bw = d.cross.in_w; qg.ldb = D; qg.N = D; qg.bias = d.cross.in_b;
+        qg.C = T.dqB; qg.ldc = D; qg.A_add = ctx->P("query_embed.weight"); qg.ld_add = D; qg.add_mod = Q; qg.add_ncols = D;
+        CHK(launch_gemm(qg, st, &ctx->err));
     }
     {
         GemmArgs kv = G0();
@@ -479,24 +525,25 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
         CHK(launch_gemm(kv, st, &ctx->err));
         AttnArgs at;
         memset(&at, 0, sizeof(at));
-        at.Q = T.dq; at.q_bs = 0; at.q_rs = D;
+        at.Q = gen ? T.dqB : T.dq; at.q_bs = gen ? (int64_t)Q * D : 0; at.q_rs = D;
         at.K = T.KV; at.k_bs = (int64_t)N * 2 * D; at.k_rs = 2 * D;
         at.V = T.KV + D; at.v_bs = at.k_bs; at.v_rs = 2 * D;
         at.O = T.Oc; at.o_bs = (int64_t)Q * D; at.o_rs = D; at.lse = T.lse_c;
         at.B = B; at.H = g.nheads; at.Nq = Q; at.Nk = N; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
         at.ws = ctx->attn_ws; at.ws_floats = ctx->attn_ws_floats;
+        at.drop_p = dropout_p; at.drop_seed = dr_dec.s(4);
         CHK(launch_attention(at, st, &ctx->err));
     }
-    const int M = B * Q;
     {
         GemmArgs op = G0();
         op.A = T.Oc; op.lda = D; op.M = M; op.K = D; op.Bw = d.cross.out_w; op.ldb = D; op.N = D; op.bias = d.cross.out_b;
-        op.C = T.Y2pre; op.ldc = D; op.res = T.t1; op.ldres = D; op.res_mod = 1;
+        op.C = T.Y2pre; op.ldc = D; op.res = gen ? T.T1B : T.t1; op.ldres = D; op.res_mod = gen ? 0 : 1;
+        op.drop_p = dropout_p; op.drop_seed = dr_dec.s(5);
         CHK(launch_gemm(op, st, &ctx->err));
     }
     CHK(launch_layernorm(T.Y2pre, nullptr, 0, d.n2w, d.n2b, nullptr, nullptr, T.T2, M, D, 1e-5f, st, &ctx->err));
-    CHK(lin_fwd(ctx, T.T2, D, M, D, d.l1w, F, d.l1b, T.Hd, F, nullptr, 1, st));
-    CHK(lin_fwd(ctx, T.Hd, F, M, F, d.l2w, D, d.l2b, T.Y3pre, D, T.T2, 0, st));
+    CHK(lin_fwd(ctx, T.T2, D, M, D, d.l1w, F, d.l1b, T.Hd, F, nullptr, 1, st, dropout_p, dr_dec.s(2)));
+    CHK(lin_fwd(ctx, T.Hd, F, M, F, d.l2w, D, d.l2b, T.Y3pre, D, T.T2, 0, st, dropout_p, dr_dec.s(3)));
     CHK(launch_layernorm(T.Y3pre, nullptr, 0, d.n3w, d.n3b, nullptr, nullptr, T.T3, M, D, 1e-5f, st, &ctx->err));
     CHK(launch_layernorm(T.T3, nullptr, 0, ctx->P("transformer.decoder.norm.weight"), ctx->P("transformer.decoder.norm.bias"),
                          nullptr, nullptr, T.hs, M, D, 1e-5f, st, &ctx->err));
@@ -537,28 +584,36 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
                       GP("transformer.decoder.norm.bias"), M, D, 1e-5f, st));
     float* dY3 = T.gA;
     CHK(launch_ln_bwd(T.Y3pre, d.n3w, dT3, nullptr, dY3, Gp(d.n3w), Gp(d.n3b), M, D, 1e-5f, st));
-    // FFN
-    CHK(lin_dgrad(ctx, dY3, D, M, D, d.l2w, F, T.gH, F, nullptr, T.Hd, st));
-    CHK(lin_wgrad(ctx, dY3, D, M, D, T.Hd, F, F, nullptr, 0, Gp(d.l2w), Gp(d.l2b), st));
+    const float dp = T.drop_p;
+    const bool gen = dp > 0.f;
+    const Drop dr_dec{dp, T.drop_seed, 200};
+    const float inv_keep = gen ? 1.f / (1.f - dp) : 1.f;
+    // FFN:  Y3pre = T2 + drop3(linear2(Hd)),  Hd = drop(relu(linear1(T2)))
+    const float* dz3 = dY3;
+    if (gen) { CHK(launch_dropout_bwd(dY3, T.gC, dr_dec.s(3), dp, (int64_t)M * D, st)); dz3 = T.gC; }
+    CHK(lin_dgrad(ctx, dz3, D, M, D, d.l2w, F, T.gH, F, nullptr, T.Hd, st, inv_keep));
+    CHK(lin_wgrad(ctx, dz3, D, M, D, T.Hd, F, F, nullptr, 0, Gp(d.l2w), Gp(d.l2b), st));
     float* dT2 = T.gC;
     CHK(lin_dgrad(ctx, T.gH, F, M, F, d.l1w, D, dT2, D, dY3, nullptr, st));
     CHK(lin_wgrad(ctx, T.gH, F, M, F, T.T2, D, D, nullptr, 0, Gp(d.l1w), Gp(d.l1b), st));
-    // norm2
+    // norm2:  Y2pre = t1 + drop2(out_proj(Oc))
     float* dY2 = T.gA;
     CHK(launch_ln_bwd(T.Y2pre, d.n2w, dT2, nullptr, dY2, Gp(d.n2w), Gp(d.n2b), M, D, 1e-5f, st));
-    // cross-attention out_proj; residual branch carries dt1 (broadcast row)
-    float* dOc = T.gC;
-    CHK(lin_dgrad(ctx, dY2, D, M, D, d.cross.out_w, D, dOc, D, nullptr, nullptr, st));
-    CHK(lin_wgrad(ctx, dY2, D, M, D, T.Oc, D, D, nullptr, 0, Gp(d.cross.out_w), Gp(d.cross.out_b), st));
-    float* dt1 = T.tmpD;                    // [D]
+    const float* dz2 = dY2;
+    if (gen) { CHK(launch_dropout_bwd(dY2, T.gC, dr_dec.s(5), dp, (int64_t)M * D, st)); dz2 = T.gC; }
+    float* dOc = T.gH;                      // [M][D] view of the big scratch
+    CHK(lin_dgrad(ctx, dz2, D, M, D, d.cross.out_w, D, dOc, D, nullptr, nullptr, st));
+    CHK(lin_wgrad(ctx, dz2, D, M, D, T.Oc, D, D, nullptr, 0, Gp(d.cross.out_w), Gp(d.cross.out_b), st));
+    float* dt1 = T.tmpD;                    // [D]  (constant path: t1 is one broadcast row)
     HIPCHK(hipMemsetAsync(T.tmpD, 0, 4 * D * sizeof(float), st));
-    CHK(launch_colsum(dY2, D, dt1, M, D, st));
+    if (!gen) CHK(launch_colsum(dY2, D, dt1, M, D, st));
+    else HIPCHK(hipMemcpyAsync(T.gT1, dY2, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));     // residual branch: dT1 = dY2
     // cross attention
     float* dKV = T.gQKV;                    // [B*N][2D]
     {
         AttnBwd t;
         memset(&t, 0, sizeof(t));
-        t.Q = T.dq; t.q_bs = 0; t.q_rs = D;
+        t.Q = gen ? T.dqB : T.dq; t.q_bs = gen ? (int64_t)Q * D : 0; t.q_rs = D;
         t.K = T.KV; t.k_bs = (int64_t)N * 2 * D; t.k_rs = 2 * D;
         t.V = T.KV + D; t.v_bs = t.k_bs; t.v_rs = 2 * D;
         t.O = T.Oc; t.dO = dOc; t.lse = T.lse_c;
@@ -566,23 +621,58 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
         t.dK = dKV; t.dk_bs = (int64_t)N * 2 * D; t.dk_rs = 2 * D;
         t.dV = dKV + D; t.dv_bs = t.dk_bs; t.dv_rs = 2 * D;
         t.B = B; t.H = H; t.Nq = Q; t.Nk = N; t.HD = hd;
+        t.drop_p = dp; t.drop_seed = dr_dec.s(4);
         CHK(attn_bwd(ctx, t, st));
     }
-    // q = (query_embed + t1) Wq^T + bq  (shared over the batch)
-    float* ddq = T.gA;                      // [Q][D]
-    CHK(launch_sum_batch(T.dqb, (int64_t)Q * D, D, ddq, B, Q, D, 0, st));
-    float* dqin = T.gC;                     // [Q][D]
-    CHK(lin_dgrad(ctx, ddq, D, Q, D, d.cross.in_w, D, dqin, D, nullptr, nullptr, st));
-    CHK(lin_wgrad(ctx, ddq, D, Q, D, T.qin, D, D, nullptr, 0, Gp(d.cross.in_w), Gp(d.cross.in_b), st));
-    CHK(launch_axpy(GP("query_embed.weight"), dqin, (int64_t)Q * D, st));
-    CHK(launch_colsum(dqin, D, dt1, Q, D, st));
-    // t1 = norm1(out_proj(b_v) + b_o)
-    float* dsa = T.tmpD + D;
-    CHK(launch_ln_bwd(T.sa_tmp, d.n1w, dt1, nullptr, dsa, Gp(d.n1w), Gp(d.n1b), 1, D, 1e-5f, st));
-    float* dbv = T.tmpD + 2 * D;
-    CHK(lin_dgrad(ctx, dsa, D, 1, D, d.self_attn.out_w, D, dbv, D, nullptr, nullptr, st));
-    CHK(lin_wgrad(ctx, dsa, D, 1, D, d.self_attn.in_b + 2 * D, D, D, nullptr, 0, Gp(d.self_attn.out_w), Gp(d.self_attn.out_b), st));
-    CHK(launch_axpy(Gp(d.self_attn.in_b) + 2 * D, dbv, D, st));
+    if (!gen) {
+        // q = (query_embed + t1) Wq^T + bq  (shared over the batch)
+        float* ddq = T.gA;                      // [Q][D]
+        CHK(launch_sum_batch(T.dqb, (int64_t)Q * D, D, ddq, B, Q, D, 0, st));
+        float* dqin = T.gC;                     // [Q][D]
+        CHK(lin_dgrad(ctx, ddq, D, Q, D, d.cross.in_w, D, dqin, D, nullptr, nullptr, st));
+        CHK(lin_wgrad(ctx, ddq, D, Q, D, T.qin, D, D, nullptr, 0, Gp(d.cross.in_w), Gp(d.cross.in_b), st));
+        CHK(launch_axpy(GP("query_embed.weight"), dqin, (int64_t)Q * D, st));
+        CHK(launch_colsum(dqin, D, dt1, Q, D, st));
+        // t1 = norm1(out_proj(b_v) + b_o)
+        float* dsa = T.tmpD + D;
+        CHK(launch_ln_bwd(T.sa_tmp, d.n1w, dt1, nullptr, dsa, Gp(d.n1w), Gp(d.n1b), 1, D, 1e-5f, st));
+        float* dbv = T.tmpD + 2 * D;
+        CHK(lin_dgrad(ctx, dsa, D, 1, D, d.self_attn.out_w, D, dbv, D, nullptr, nullptr, st));
+        CHK(lin_wgrad(ctx, dsa, D, 1, D, d.self_attn.in_b + 2 * D, D, D, nullptr, 0, Gp(d.self_attn.out_w), Gp(d.self_attn.out_b), st));
+        CHK(launch_axpy(Gp(d.self_attn.in_b) + 2 * D, dbv, D, st));
+    } else {
+        // q[b] = (T1[b] + query_embed) Wq^T + bq
+        float* dqin = T.gA;                     // [M][D]
+        CHK(lin_dgrad(ctx, T.dqb, D, M, D, d.cross.in_w, D, dqin, D, nullptr, nullptr, st));
+        CHK(lin_wgrad(ctx, T.dqb, D, M, D, T.T1B, D, D, ctx->P("query_embed.weight"), Q, Gp(d.cross.in_w), Gp(d.cross.in_b), st));
+        CHK(launch_sum_batch(dqin, (int64_t)Q * D, D, GP("query_embed.weight"), B, Q, D, 1, st));
+        CHK(launch_axpy(T.gT1, dqin, (int64_t)M * D, st));
+        // T1 = norm1(drop1(out_proj(sO)))
+        CHK(launch_ln_bwd(T.saB, d.n1w, T.gT1, nullptr, T.dsaB, Gp(d.n1w), Gp(d.n1b), M, D, 1e-5f, st));
+        CHK(launch_dropout_bwd(T.dsaB, T.gT1, dr_dec.s(1), dp, (int64_t)M * D, st));            // gT1 := d(out_proj output)
+        float* dsO = T.gA;
+        CHK(lin_dgrad(ctx, T.gT1, D, M, D, d.self_attn.out_w, D, dsO, D, nullptr, nullptr, st));
+        CHK(lin_wgrad(ctx, T.gT1, D, M, D, T.sO, D, D, nullptr, 0, Gp(d.self_attn.out_w), Gp(d.self_attn.out_b), st));
+        // self-attention: q = k = query_pos (shared over the batch), every value row = b_v
+        AttnBwd t;
+        memset(&t, 0, sizeof(t));
+        t.Q = T.qkd; t.q_bs = 0; t.q_rs = 2 * D;
+        t.K = T.qkd + D; t.k_bs = 0; t.k_rs = 2 * D;
+        t.V = d.self_attn.in_b + 2 * D; t.v_bs = 0; t.v_rs = 0;
+        t.O = T.sO; t.dO = dsO; t.lse = T.lse_s;
+        t.dQ = T.dqkB; t.dq_bs = (int64_t)Q * 2 * D; t.dq_rs = 2 * D;
+        t.dK = T.dqkB + D; t.dk_bs = t.dq_bs; t.dk_rs = 2 * D;
+        t.dV = T.dvB; t.dv_bs = (int64_t)Q * D; t.dv_rs = D;
+        t.B = B; t.H = H; t.Nq = Q; t.Nk = Q; t.HD = hd;
+        t.drop_p = dp; t.drop_seed = dr_dec.s(0);
+        CHK(attn_bwd(ctx, t, st));
+        CHK(launch_colsum(T.dvB, D, Gp(d.self_attn.in_b) + 2 * D, M, D, st));                     // d b_v (sum over keys and batch)
+        CHK(launch_sum_batch(T.dqkB, (int64_t)Q * 2 * D, 2 * D, T.dqk_d, B, Q, 2 * D, 0, st));    // q/k are shared over the batch
+        CHK(lin_dgrad(ctx, T.dqk_d, 2 * D, Q, 2 * D, d.self_attn.in_w, D, T.tmpQD, D, nullptr, nullptr, st));
+        CHK(launch_axpy(GP("query_embed.weight"), T.tmpQD, (int64_t)Q * D, st));
+        CHK(lin_wgrad(ctx, T.dqk_d, 2 * D, Q, 2 * D, ctx->P("query_embed.weight"), D, D, nullptr, 0, Gp(d.self_attn.in_w),
+                      Gp(d.self_attn.in_b), st));
+    }
     // k = (memory + pos) Wk^T, v = memory Wv^T
     float* dmem = T.gB;
     CHK(lin_dgrad(ctx, dKV, 2 * D, B * N, 2 * D, d.cross.in_w + (int64_t)D * D, D, dmem, D, nullptr, nullptr, st));
@@ -599,7 +689,8 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
     }
     // ---- encoder layers, last to first.  dOut lives in gB; each layer returns its dIn in gB again.
     for (int l = g.enc_layers - 1; l >= 0; --l)
-        CHK(enc_bwd(ctx, ctx->enc[l], T.en[l], T.gB, T.gB, ctx->pos_tokens, B, N, nullptr, dpos2, st));
+        CHK(enc_bwd(ctx, ctx->enc[l], T.en[l], T.gB, T.gB, ctx->pos_tokens, B, N, nullptr, dpos2,
+                    Drop{dp, T.drop_seed, (uint32_t)(100 + 8 * l)}, st));
     float* dX = T.gB;                       // grad wrt the token matrix [B][N][D]
     // token 1: proprio = W_s qpos + b_s
     CHK(launch_small_linear_wgrad(dX + D, (int64_t)N * D, T.qpos, S, GP("input_proj_robot_state.weight"), B, D, S, st));
@@ -689,7 +780,8 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
         CHK(lin_wgrad(ctx, T.d_latent_info, 2 * L, B, 2 * L, T.cv_out, (int64_t)n * D, D, nullptr, 0, GP("latent_proj.weight"),
                       GP("latent_proj.bias"), st));
         for (int l = g.enc_layers - 1; l >= 0; --l)
-            CHK(enc_bwd(ctx, ctx->cvae[l], T.cv[l], T.gB, T.gB, ctx->P("pos_table"), B, n, T.ckpm, nullptr, st));
+            CHK(enc_bwd(ctx, ctx->cvae[l], T.cv[l], T.gB, T.gB, ctx->P("pos_table"), B, n, T.ckpm, nullptr,
+                        Drop{dp, T.drop_seed, (uint32_t)(8 * l)}, st));
         float* dXc = T.gB;
         CHK(launch_sum_batch(dXc, (int64_t)n * D, D, GP("cls_embed.weight"), B, 1, D, 1, st));
         CHK(launch_small_linear_wgrad(dXc + D, (int64_t)n * D, T.qpos, S, GP("encoder_joint_proj.weight"), B, D, S, st));

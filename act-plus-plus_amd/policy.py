@@ -73,7 +73,8 @@ class ACTPolicy:
         self.model.load_state_dict(generate_state_dict(self.cfg, seed=init_seed))
         self.training = True
         self.optimizer = _AdamW(self.model, args_override["lr"], args_override.get("lr_backbone", 1e-5), self.cfg.weight_decay)
-        self.train_dropout = float(args_override.get("train_dropout", 0.0))
+        self.train_dropout = float(args_override.get("train_dropout", self.cfg.dropout))
+        self.dropout_seed = int(args_override.get("seed", 0))
         print(f"KL Weight {self.kl_weight}")
         print(f"Use Depth: {self.use_depth}")
 
@@ -81,7 +82,11 @@ class ACTPolicy:
         if actions is not None:                                # training / validation (policy.py:288-320)
             eps = getattr(self, "next_eps", None)
             self.next_eps = None
-            out = self.model.forward_train(qpos, image, actions, is_pad, eps=eps, dropout_p=0.0)
+            # train mode: dropout as in the reference (detr/main.py:45, 0.1); eval/validation: off (nn.Module.eval())
+            p = self.train_dropout if self.training else 0.0
+            self._drop_step = getattr(self, "_drop_step", 0) + 1
+            out = self.model.forward_train(qpos, image, actions, is_pad, eps=eps, dropout_p=p,
+                                           dropout_seed=(self.dropout_seed << 20) + self._drop_step)
             return {"l1": out["l1"], "kl": out["kl"], "loss": _Loss.wrap(out["loss"], self)}
         # inference: ImageNet normalisation (policy.py:268-272) is fused into the conv1 loader
         return self.model.forward_infer(qpos, image)

@@ -96,6 +96,10 @@ typedef struct actmi_gemm_desc {
     int32_t groups_inner;      /* >0: group g = (g / groups_inner, g % groups_inner) with the second-level strides below */
     int64_t gA2, gB2, gC2, gRes2;
     int64_t gMask, gC2out;     /* per-group strides of mask / C2 (first level) */
+    /* dropout on the (scaled, biased, ReLU'd when no residual) result before the residual is added; the mask is a pure
+     * function of (drop_seed, output element index), kept values are scaled by 1/(1-drop_p); drop_p = 0 disables */
+    float drop_p;
+    uint64_t drop_seed;
 } actmi_gemm_desc;
 
 /* Multi-head attention descriptor: softmax(scale * q k^T [+ key padding mask]) v per (batch, head).
@@ -114,6 +118,9 @@ typedef struct actmi_attn_desc {
      * nsplit * B * Nq * (H*HD + 2*H); ws = NULL disables splitting. */
     float* ws;
     int64_t ws_floats;
+    /* dropout on the attention weights (nn.MultiheadAttention dropout): mask = f(drop_seed, ((b*H+h)*Nq+q)*Nk+key) */
+    float drop_p;
+    uint64_t drop_seed;
 } actmi_attn_desc;
 
 int actmi_version(void);

@@ -177,3 +177,79 @@ def test_training_full_size_gradients_and_adamw():
     d = eng.device
     a1 = eng.forward_infer(torch.from_numpy(inp["qpos"]).to(d), torch.from_numpy(inp["image_u8"]).to(d))
     assert torch.isfinite(a1).all()
+
+
+def test_dropout_epilogue_statistics_and_determinism():
+    g = torch.Generator().manual_seed(0)
+    d = torch.device("cuda:0")
+    M, N, K, p = 512, 384, 64, 0.3
+    A, Wt, b = torch.randn(M, K, generator=g).to(d), torch.randn(N, K, generator=g).to(d), torch.randn(N, generator=g).to(d)
+    res = torch.randn(M, N, generator=g).to(d)
+    base = ops.gemm(A, Wt, bias=b)
+    y1 = ops.gemm(A, Wt, bias=b, res=res, drop_p=p, drop_seed=7)
+    y2 = ops.gemm(A, Wt, bias=b, res=res, drop_p=p, drop_seed=7)
+    y3 = ops.gemm(A, Wt, bias=b, res=res, drop_p=p, drop_seed=8)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)                  # pure function of (seed, element)
+    z = y1 - res                                                             # dropout acts before the residual add
+    dropped = (z == 0)
+    frac = float(dropped.float().mean())
+    assert abs(frac - p) < 0.01
+    kept = ~dropped
+    assert torch.allclose(z[kept], base[kept] / (1 - p), rtol=1e-5, atol=1e-5)
+    # attention-weight dropout: E[out] == no-dropout output (unbiased), rows differ by seed
+    B, H, Nq, Nk, hd = 2, 4, 64, 96, 16
+    q, k, v = (torch.randn(B, n, H * hd, generator=g).to(d) for n in (Nq, Nk, Nk))
+    o0 = ops.attention(q, k, v, H)
+    acc = torch.zeros_like(o0)
+    for s in range(64):
+        acc += ops.attention(q, k, v, H, drop_p=0.2, drop_seed=100 + s)
+    assert float(((acc / 64) - o0).abs().mean()) < 0.05 * float(o0.abs().mean()) + 0.02
+
+
+def test_training_gradients_with_dropout_by_finite_differences():
+    """With a fixed dropout seed the loss is a deterministic function of the weights: check the analytic backward
+    (including the general decoder self-attention path that dropout activates) against central differences."""
+    from actmi.config import tiny_config
+    cfg = tiny_config(kl_weight=1)
+    sd_np = W.generate_state_dict(cfg, seed=21)
+    B, p, seed = 2, 0.25, 1234567
+    eng = ACTEngine(cfg, max_batch=B, training=True)
+    inp = W.generate_inputs(cfg, B, seed=9, with_actions=True)
+    d = eng.device
+    t = {k: torch.from_numpy(v).to(d) for k, v in inp.items()}
+
+    def loss_of(sd):
+        eng.load_state_dict(sd)
+        eng.finalize()
+        out = eng.forward_train(t["qpos"], t["image_u8"], t["actions"], t["is_pad"], eps=t["eps"], dropout_p=p, dropout_seed=seed)
+        return float(out["loss"].double()), out
+
+    l0, _ = loss_of(sd_np)
+    l0b, _ = loss_of(sd_np)
+    assert l0 == l0b                                                       # same seed, same loss
+    lp, _ = loss_of(sd_np)
+    eng.zero_grad()
+    eng.backward(1.0)
+    keys = ["transformer.decoder.layers.0.self_attn.in_proj_weight", "transformer.decoder.layers.0.self_attn.out_proj.weight",
+            "transformer.decoder.layers.0.self_attn.in_proj_bias", "query_embed.weight",
+            "transformer.decoder.layers.0.multihead_attn.in_proj_weight", "transformer.decoder.layers.0.linear2.weight",
+            "transformer.encoder.layers.1.linear1.weight", "transformer.encoder.layers.0.self_attn.out_proj.weight",
+            "encoder.layers.0.self_attn.in_proj_weight", "latent_proj.weight", "action_head.weight",
+            "backbones.1.0.body.layer3.0.conv1.weight", "input_proj.weight", "transformer.decoder.layers.0.norm1.weight"]
+    grads = {k: eng.grad(k).cpu().numpy().copy() for k in keys}
+    # the dropped self-attention makes the q/k gradients non-zero (they are exactly zero without dropout)
+    assert np.abs(grads["transformer.decoder.layers.0.self_attn.in_proj_weight"][:2 * cfg.hidden_dim]).max() > 0
+    worst = 0.0
+    for k in keys:
+        g = grads[k]
+        idx = np.unravel_index(np.argmax(np.abs(g)), g.shape)            # the most sensitive element: best signal/noise
+        ga = float(g[idx])
+        h = 2e-2 if abs(ga) < 0.5 else 5e-3
+        sp, sm = {kk: vv.copy() for kk, vv in sd_np.items()}, {kk: vv.copy() for kk, vv in sd_np.items()}
+        sp[k][idx] += h
+        sm[k][idx] -= h
+        fd = (loss_of(sp)[0] - loss_of(sm)[0]) / (float(sp[k][idx]) - float(sm[k][idx]))
+        err = abs(fd - ga) / max(abs(ga), 1e-3)
+        print(f"{k}{list(idx)}: analytic {ga:+.5f} finite-diff {fd:+.5f} rel.err {err:.3f}")
+        worst = max(worst, err)
+        assert err < 0.08, (k, ga, fd)
