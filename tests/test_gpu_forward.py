@@ -131,3 +131,23 @@ def test_state_dict_round_trip_and_errors():
     with pytest.raises(ValueError):
         eng.forward_infer(torch.zeros(3, cfg.state_dim).cuda(),
                           torch.zeros(3, cfg.num_cams, cfg.image_h, cfg.image_w, 3, dtype=torch.uint8).cuda())
+
+
+def test_hipgraph_replay_equals_eager():
+    """The forward allocates nothing and never syncs: captured into a hipGraph it must give bit-identical results."""
+    from actmi.config import tiny_config
+    from actmi import ops
+    cfg = tiny_config(camera_names=["a", "b", "c"])
+    eng = _engine(cfg, W.generate_state_dict(cfg, seed=3), 4)
+    ens_g = ops.TemporalEnsemble(4, cfg.num_queries, cfg.action_dim, 0.01, eng.device)
+    ens_e = ops.TemporalEnsemble(4, cfg.num_queries, cfg.action_dim, 0.01, eng.device)
+    replay = eng.capture_infer(4, with_ensemble=ens_g)
+    for t in range(3):
+        inp = W.generate_inputs(cfg, 4, seed=50 + t)
+        q, im = torch.from_numpy(inp["qpos"]).cuda(), torch.from_numpy(inp["image_u8"]).cuda()
+        a_g, raw_g = replay(q, im)
+        a_g, raw_g = a_g.clone(), raw_g.clone()
+        a_e = eng.forward_infer(q, im).clone()
+        raw_e = ens_e.step(a_e).clone()
+        assert torch.equal(a_g, a_e)
+        assert torch.equal(raw_g, raw_e)
