@@ -209,6 +209,19 @@ class ACTEngine:
         L.check(self.lib.actmi_adamw_step(self.h, lr, lr_backbone, weight_decay, beta1, beta2, eps, int(step),
                                           L.current_stream_ptr()), self.h, "adamw_step")
 
+    def grad_arena(self) -> torch.Tensor:
+        """Flat float32 view (no copy) of the whole gradient arena, for data-parallel all-reduce."""
+        p, n = C.c_void_p(), C.c_int64()
+        L.check(self.lib.actmi_grad_arena(self.h, C.byref(p), C.byref(n)), self.h, "grad_arena")
+        return _from_ptr(p.value, n.value, self.device)
+
+    def allreduce_grads(self, group=None, bucket_mb: int = 64):
+        """Sum the gradient arena over the data-parallel ranks in buckets (RCCL when the backend is nccl).  Call
+        ``backward(loss_scale=1/world)`` first so that the sum is the mean over the global batch (the reference's loss
+        is a per-sample mean, policy.py:314-318,386-387)."""
+        from .dist_utils import allreduce_buckets
+        allreduce_buckets(self.grad_arena(), bucket_mb * (1 << 20) // 4, group)
+
     def grad(self, key: str) -> torch.Tensor:
         """Copy of the gradient of one state_dict entry (shape of the parameter)."""
         p, n = C.c_void_p(), C.c_int64()

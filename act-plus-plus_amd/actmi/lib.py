@@ -89,6 +89,7 @@ def load():
         "actmi_zero_grad": ([vp, vp], i32),
         "actmi_adamw_step": ([vp, f32, f32, f32, f32, f32, f32, i64, vp], i32),
         "actmi_grad_ptr": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i64)], i32),
+        "actmi_grad_arena": ([vp, C.POINTER(vp), C.POINTER(i64)], i32),
         "actmi_ensemble_step": ([vp, vp, vp, f64, vp, vp, i32, i32, i32, vp], i32),
         "actmi_op_gemm": ([C.POINTER(GemmDesc), vp], i32),
         "actmi_op_attention": ([C.POINTER(AttnDesc), vp], i32),

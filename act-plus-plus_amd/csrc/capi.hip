@@ -99,6 +99,14 @@ int actmi_grad_ptr(actmi_handle h, const char* key, void** dev_ptr, int64_t* num
     return 0;
 }
 
+int actmi_grad_arena(actmi_handle h, void** dev_ptr, int64_t* nfloats) {
+    if (!h) return ACTMI_E_INVALID;
+    if (!h->train) return bad(h, "handle was created without enable_training", ACTMI_E_STATE);
+    if (dev_ptr) *dev_ptr = h->train->gbase;
+    if (nfloats) *nfloats = h->ptotal;
+    return 0;
+}
+
 int actmi_ensemble_step(float* ring, int32_t* tcount, const float* chunk, double k, double* out, uint8_t* populated, int E,
                         int Q, int A, void* stream) {
     if (!ring || !tcount || !chunk || !out || Q < 1 || A < 1 || A > 64) return ACTMI_E_INVALID;

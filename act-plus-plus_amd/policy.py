@@ -34,7 +34,11 @@ class _Loss(torch.Tensor):
         return out
 
     def backward(self, *a, **k):      # noqa: D401
-        self._policy.model.backward(1.0)
+        import torch.distributed as dist
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self._policy.model.backward(1.0 / world)       # data parallel: mean over the global batch
+        if world > 1:
+            self._policy.model.allreduce_grads()
 
 
 class _AdamW:

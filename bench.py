@@ -201,7 +201,9 @@ def bench_train(args, cfg, B, dev, rank, world, dist):
     def step(i):
         eng.zero_grad()
         out = eng.forward_train(t["qpos"], t["image_u8"], t["actions"], t["is_pad"], eps=t["eps"])
-        eng.backward(1.0)
+        eng.backward(1.0 / world)
+        if world > 1:
+            eng.allreduce_grads()          # data-parallel training: bucketed gradient all-reduce over RCCL / xGMI
         eng.adamw_step(1e-5, 1e-5, 1e-4, step=i + 1)
         return out
 
@@ -239,7 +241,7 @@ def bench_train(args, cfg, B, dev, rank, world, dist):
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ACT training step, per-GPU batch {B}, 4 cams 480x640, hidden 512, ff 3200, dropout 0",
-                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"replicas x{world}"},
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": PEAK_FP32_MATRIX_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
                          "avg_launch_us": dom["ms"] * 1e3 / dom["count"]},

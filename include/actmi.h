@@ -157,6 +157,8 @@ int actmi_zero_grad(actmi_handle h, void* stream);
 int actmi_adamw_step(actmi_handle h, float lr, float lr_backbone, float weight_decay, float beta1, float beta2,
                      float eps, int64_t step, void* stream);
 int actmi_grad_ptr(actmi_handle h, const char* key, void** dev_ptr, int64_t* numel);
+/* the whole gradient arena (same layout as the parameter arena) for bucketed data-parallel all-reduce over RCCL */
+int actmi_grad_arena(actmi_handle h, void** dev_ptr, int64_t* nfloats);
 
 /* ---- temporal ensembling over E episodes (imitate_episodes.py:338-339, 402-411) ------------------- */
 /* ring [E][Q][Q][A] f32 zero-initialised, tcount [E] i32 zero-initialised, chunk [E][Q][A] f32;
