@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
         ("alpha", C.c_float), ("groups_inner", C.c_int32),
         ("gA2", C.c_int64), ("gB2", C.c_int64), ("gC2", C.c_int64), ("gRes2", C.c_int64),
         ("gMask", C.c_int64), ("gC2out", C.c_int64),
-        ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
+        ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("stamps", C.c_void_p),
     ]
 
 

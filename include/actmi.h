@@ -100,6 +100,9 @@ typedef struct actmi_gemm_desc {
      * function of (drop_seed, output element index), kept values are scaled by 1/(1-drop_p); drop_p = 0 disables */
     float drop_p;
     uint64_t drop_seed;
+    /* diagnostic: when non-NULL, thread 0 of every block writes 4 shader-clock stamps (s_memtime) here:
+     * [block][0] entry, [1] first LDS stage ready, [2] K loop done, [3] epilogue done.  Never set on the product path. */
+    uint64_t* stamps;
 } actmi_gemm_desc;
 
 /* Multi-head attention descriptor: softmax(scale * q k^T [+ key padding mask]) v per (batch, head).

@@ -7,6 +7,8 @@ import torch
 from actmi import ops
 
 dev = torch.device("cuda:0")
+VENDOR = os.environ.get("GEMM_BENCH_VENDOR") == "1"
+torch.backends.cuda.matmul.allow_tf32 = False
 
 def timeit(fn, iters=20):
     for _ in range(3): fn()
@@ -21,7 +23,11 @@ def lin(M, N, K, tag):
     A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
     out = torch.empty(M, N, device=dev)
     ms = timeit(lambda: ops.gemm(A, W, bias=b, out=out))
-    print(f"{tag:28s} M={M:6d} N={N:5d} K={K:5d}  {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TF")
+    line = f"{tag:28s} M={M:6d} N={N:5d} K={K:5d}  {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TF"
+    if VENDOR:      # the vendor library (rocBLAS / hipBLASLt behind torch.addmm), same shape, for orientation only
+        ms2 = timeit(lambda: torch.addmm(b, A, W.t(), out=out))
+        line += f"   | torch.addmm {ms2*1e3:8.1f} us {2*M*N*K/ms2/1e9:7.1f} TF"
+    print(line)
 
 def conv(G, B, H, W_, Cin, Cout, k, s, p, tag):
     x = torch.randn(G, B, H, W_, Cin, device=dev); w = torch.randn(G, Cout, k, k, Cin, device=dev)
