@@ -10,8 +10,20 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+PREC = {None: 0, "f32": 1, "f16x3": 2}
+
+
+def split16(w):
+    """fp16-split image of an f32 cuda tensor (numel % 4 == 0): what `gemm(..., prec="f16x3", w_split=True)` consumes."""
+    lib = L.load()
+    w = w.contiguous()
+    out = torch.empty_like(w)
+    L.check(lib.actmi_op_split16(_p(w), _p(out), w.numel(), L.current_stream_ptr()), None, "op_split16")
+    return out
+
+
 def gemm(A, W, bias=None, scale=None, res=None, res_mod=0, relu=False, a_add=None, add_mod=0, add_ncols=0, rowmap=None,
-         out=None, out_rows=None, drop_p=0.0, drop_seed=0):
+         out=None, out_rows=None, drop_p=0.0, drop_seed=0, prec=None, w_split=False):
     """out[rowmap(m)] = act((A' @ W.T) * scale + bias + res[m % res_mod]); A [M,K], W [N,K] row-major f32 cuda."""
     lib = L.load()
     M, K = A.shape
@@ -32,11 +44,12 @@ def gemm(A, W, bias=None, scale=None, res=None, res_mod=0, relu=False, a_add=Non
     d.rowmap = rowmap.data_ptr() if rowmap is not None else None
     d.M, d.N, d.K, d.groups = M, N, K, 1
     d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)
+    d.prec, d.b_split = PREC[prec], 1 if w_split else 0
     L.check(lib.actmi_op_gemm(C.byref(d), L.current_stream_ptr()), None, "op_gemm")
     return out
 
 
-def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1, pad=1):
+def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1, pad=1, prec=None, w_split=False):
     """x [G,B,H,W,Cin] camera-major NHWC; w_ohwi [G,Cout,KH,KW,Cin]; scale/bias [G,Cout]; returns [G,B,Ho,Wo,Cout]."""
     lib = L.load()
     G, B, H, W, Cin = x.shape
@@ -57,6 +70,7 @@ def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1
     d.M, d.N, d.K, d.groups = B * Ho * Wo, Cout, KH * KW * Cin, G
     d.gA, d.gB, d.gSB = B * H * W * Cin, Cout * KH * KW * Cin, Cout
     d.gC = d.gRes = B * Ho * Wo * Cout
+    d.prec, d.b_split = PREC[prec], 1 if w_split else 0
     L.check(lib.actmi_op_gemm(C.byref(d), L.current_stream_ptr()), None, "op_gemm(conv)")
     return out
 

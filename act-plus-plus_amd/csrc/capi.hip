@@ -119,6 +119,13 @@ int actmi_op_gemm(const actmi_gemm_desc* d, void* stream) {
     return launch_gemm(*d, S(stream), &g_op_error);
 }
 
+int actmi_op_split16(const float* src, float* dst, int64_t nfloats, void* stream) {
+    g_op_error.clear();
+    const int rc = launch_split16(src, dst, nfloats, S(stream));
+    if (rc != 0) g_op_error = "split16: nfloats must be a multiple of 4 and both pointers 16-byte aligned";
+    return rc == 0 ? 0 : ACTMI_E_INVALID;
+}
+
 int actmi_op_attention(const actmi_attn_desc* d, void* stream) {
     if (!d) return ACTMI_E_INVALID;
     g_op_error.clear();

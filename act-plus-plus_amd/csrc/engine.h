@@ -20,6 +20,7 @@ struct ConvLayer {
     int cin, cout, k, stride, pad, H, W, Ho, Wo;
     int K = 0;
     float* w = nullptr;       // [cam][cout][K], K index (r,s,c)
+    float* w16 = nullptr;     // the same, fp16-split (f16x3 GEMM)
     float* scale = nullptr;   // [cam][cout]
     float* bias = nullptr;
 };
@@ -73,6 +74,8 @@ struct actmi_ctx {
     std::unordered_map<std::string, int> index;
     std::vector<void*> allocs;
     float* pbase = nullptr;
+    float* p16base = nullptr;          // fp16-split image of the parameter arena (B operands of the f16x3 GEMM)
+    int gemm_prec = 0;                 // ACTMI_PREC_* used by the forward GEMMs of this handle
     int64_t ptotal = 0;
     bool finalized = false;
     // geometry
@@ -99,6 +102,8 @@ struct actmi_ctx {
 };
 
 int engine_create(const actmi_config* cfg, actmi_ctx** out);
+// forward GEMMs of a handle go through here: applies the handle's precision and swaps in pre-split weights
+int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st);
 int engine_destroy(actmi_ctx* ctx);
 const char* engine_create_error();
 int engine_finalize(actmi_ctx* ctx, hipStream_t st);

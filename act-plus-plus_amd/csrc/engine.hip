@@ -149,6 +149,25 @@ int dev_alloc(actmi_ctx* ctx, float** p, int64_t nfloats) {
     return 0;
 }
 
+}  // namespace
+
+int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
+    a.prec = ctx->gemm_prec;
+    if (ctx->gemm_prec == ACTMI_PREC_F16X3 && a.tb == 0) {
+        // B is a weight matrix: use its pre-split image (same offsets) where one exists
+        if (a.Bw >= ctx->pbase && a.Bw < ctx->pbase + ctx->ptotal) {
+            a.Bw = ctx->p16base + (a.Bw - ctx->pbase);
+            a.b_split = 1;
+        } else {
+            for (const ConvLayer& cl : ctx->convs)
+                if (a.Bw == cl.w) { a.Bw = cl.w16; a.b_split = 1; break; }
+        }
+    }
+    return launch_gemm(a, st, &ctx->err);
+}
+
+namespace {
+
 MhaW mha_w(actmi_ctx* c, const std::string& p) {
     MhaW m;
     m.in_w = c->P(p + "in_proj_weight");
@@ -236,6 +255,13 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
     int rc;
     if ((rc = dev_alloc(ctx, &ctx->pbase, ctx->ptotal))) return fail(rc);
     if (hipMemset(ctx->pbase, 0, ctx->ptotal * sizeof(float)) != hipSuccess) { ctx->err = "hipMemset failed"; return fail(ACTMI_E_LAUNCH); }
+    {
+        // forward precision of this handle: fp16-split products unless ACTMI_GEMM_PREC=f32 asks for the native fp32 MFMA
+        const char* e = getenv("ACTMI_GEMM_PREC");
+        ctx->gemm_prec = (e && e[0] == 'f' && e[1] == '3') ? ACTMI_PREC_F32 : ACTMI_PREC_F16X3;
+        if (ctx->ptotal & 3) { ctx->err = "parameter arena not a multiple of 4 floats"; return fail(ACTMI_E_LAUNCH); }
+        if ((rc = dev_alloc(ctx, &ctx->p16base, ctx->ptotal))) return fail(rc);
+    }
     resolve_layers(ctx);
 
     // ---- conv layer table + packed weights
@@ -261,6 +287,7 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
         for (auto& cl : ctx->convs) {
             cl.K = cl.k * cl.k * cl.cin;
             if ((rc = dev_alloc(ctx, &cl.w, (int64_t)C * cl.cout * cl.K))) return fail(rc);
+            if ((rc = dev_alloc(ctx, &cl.w16, (int64_t)C * cl.cout * cl.K))) return fail(rc);
             if ((rc = dev_alloc(ctx, &cl.scale, (int64_t)C * cl.cout))) return fail(rc);
             if ((rc = dev_alloc(ctx, &cl.bias, (int64_t)C * cl.cout))) return fail(rc);
         }
@@ -343,6 +370,11 @@ int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st) {
                                cl.cout, st));
         }
     }
+    if (ctx->gemm_prec == ACTMI_PREC_F16X3) {
+        CHK(launch_split16(ctx->pbase, ctx->p16base, ctx->ptotal, st));
+        for (const ConvLayer& cl : ctx->convs)
+            CHK(launch_split16(cl.w, cl.w16, (int64_t)C * cl.cout * cl.K, st));
+    }
     // learned rows of the token position table (transformer.py:91-92)
     HIPCHK(hipMemcpyAsync(ctx->pos_tokens, ctx->P("additional_pos_embed.weight"), 2 * D * sizeof(float),
                           hipMemcpyDeviceToDevice, st));
@@ -351,11 +383,11 @@ int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st) {
     {
         const DecW& d = ctx->dec[0];
         GemmArgs a = linear_args(d.self_attn.in_b + 2 * D, D, 1, D, d.self_attn.out_w, D, d.self_attn.out_b, ctx->tmp_vec, D);
-        CHK(launch_gemm(a, st, &ctx->err));
+        CHK(ctx_gemm(ctx, a, st));
         CHK(launch_layernorm(ctx->tmp_vec, nullptr, 0, d.n1w, d.n1b, nullptr, nullptr, ctx->dec_t1, 1, D, 1e-5f, st, &ctx->err));
         GemmArgs q = linear_args(ctx->P("query_embed.weight"), D, Q, D, d.cross.in_w, D, d.cross.in_b, ctx->dec_q, D);
         q.A_add = ctx->dec_t1; q.ld_add = D; q.add_mod = 1; q.add_ncols = D;
-        CHK(launch_gemm(q, st, &ctx->err));
+        CHK(ctx_gemm(ctx, q, st));
     }
     return 0;
 }
@@ -439,7 +471,7 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
         a.groups = C;
         a.gA = (int64_t)B * cl.H * cl.W * cl.cin; a.gB = (int64_t)cl.cout * cl.K; a.gSB = cl.cout;
         a.gC = (int64_t)a.M * cl.cout; a.gRes = a.gC;
-        return launch_gemm(a, st, &ctx->err);
+        return ctx_gemm(ctx, a, st);
     };
     size_t ci = 0;
     for (int li = 1; li <= 4; ++li) {
@@ -470,7 +502,7 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
     GemmArgs ip = linear_args(cur, 8 * w0, C * B * ctx->P_, 8 * w0, ctx->P("input_proj.weight"), D,
                               ctx->P("input_proj.bias"), ctx->X, D);
     ip.rowmap = ctx->rowmap;
-    CHK(launch_gemm(ip, st, &ctx->err));
+    CHK(ctx_gemm(ctx, ip, st));
     return 0;
 }
 
@@ -481,7 +513,7 @@ int engine_encoder_layer(actmi_ctx* ctx, const EncW& w, float* x, const float* p
     const int D = g.hidden_dim, F = g.dim_feedforward, M = B * n, hd = D / g.nheads;
     GemmArgs qkv = linear_args(x, D, M, D, w.attn.in_w, 3 * D, w.attn.in_b, ctx->QKV, 3 * D);
     qkv.A_add = pos; qkv.ld_add = D; qkv.add_mod = n; qkv.add_ncols = 2 * D;     // q = k = x + pos, v = x
-    CHK(launch_gemm(qkv, st, &ctx->err));
+    CHK(ctx_gemm(ctx, qkv, st));
     AttnArgs at;
     memset(&at, 0, sizeof(at));
     at.Q = ctx->QKV; at.q_bs = (int64_t)n * 3 * D; at.q_rs = 3 * D;
@@ -494,14 +526,14 @@ int engine_encoder_layer(actmi_ctx* ctx, const EncW& w, float* x, const float* p
     CHK(launch_attention(at, st, &ctx->err));
     GemmArgs op = linear_args(ctx->ATT, D, M, D, w.attn.out_w, D, w.attn.out_b, ctx->Y, D);
     op.res = x; op.ldres = D;
-    CHK(launch_gemm(op, st, &ctx->err));
+    CHK(ctx_gemm(ctx, op, st));
     CHK(launch_layernorm(ctx->Y, nullptr, 0, w.n1w, w.n1b, nullptr, nullptr, ctx->X1, M, D, 1e-5f, st, &ctx->err));
     GemmArgs f1 = linear_args(ctx->X1, D, M, D, w.l1w, F, w.l1b, ctx->Hb, F);
     f1.relu = 1;
-    CHK(launch_gemm(f1, st, &ctx->err));
+    CHK(ctx_gemm(ctx, f1, st));
     GemmArgs f2 = linear_args(ctx->Hb, F, M, F, w.l2w, D, w.l2b, ctx->Y, D);
     f2.res = ctx->X1; f2.ldres = D;
-    CHK(launch_gemm(f2, st, &ctx->err));
+    CHK(ctx_gemm(ctx, f2, st));
     CHK(launch_layernorm(ctx->Y, nullptr, 0, w.n2w, w.n2b, nullptr, nullptr, x, M, D, 1e-5f, st, &ctx->err));
     return 0;
 }
@@ -514,7 +546,7 @@ int engine_decoder_infer(actmi_ctx* ctx, int B, float* a_hat, hipStream_t st) {
     float* KV = ctx->QKV;   // [B*N][2D]
     GemmArgs kv = linear_args(ctx->X, D, B * N, D, d.cross.in_w + (int64_t)D * D, 2 * D, d.cross.in_b + D, KV, 2 * D);
     kv.A_add = ctx->pos_tokens; kv.ld_add = D; kv.add_mod = N; kv.add_ncols = D;      // k = memory + pos, v = memory
-    CHK(launch_gemm(kv, st, &ctx->err));
+    CHK(ctx_gemm(ctx, kv, st));
     AttnArgs at;
     memset(&at, 0, sizeof(at));
     at.Q = ctx->dec_q; at.q_bs = 0; at.q_rs = D;
@@ -527,19 +559,19 @@ int engine_decoder_infer(actmi_ctx* ctx, int B, float* a_hat, hipStream_t st) {
     const int M = B * Q;
     GemmArgs op = linear_args(ctx->dO, D, M, D, d.cross.out_w, D, d.cross.out_b, ctx->dY, D);
     op.res = ctx->dec_t1; op.ldres = D; op.res_mod = 1;
-    CHK(launch_gemm(op, st, &ctx->err));
+    CHK(ctx_gemm(ctx, op, st));
     CHK(launch_layernorm(ctx->dY, nullptr, 0, d.n2w, d.n2b, nullptr, nullptr, ctx->dT2, M, D, 1e-5f, st, &ctx->err));
     GemmArgs f1 = linear_args(ctx->dT2, D, M, D, d.l1w, F, d.l1b, ctx->dH, F);
     f1.relu = 1;
-    CHK(launch_gemm(f1, st, &ctx->err));
+    CHK(ctx_gemm(ctx, f1, st));
     GemmArgs f2 = linear_args(ctx->dH, F, M, F, d.l2w, D, d.l2b, ctx->dY, D);
     f2.res = ctx->dT2; f2.ldres = D;
-    CHK(launch_gemm(f2, st, &ctx->err));
+    CHK(ctx_gemm(ctx, f2, st));
     CHK(launch_layernorm(ctx->dY, nullptr, 0, d.n3w, d.n3b, ctx->P("transformer.decoder.norm.weight"),
                          ctx->P("transformer.decoder.norm.bias"), ctx->hs, M, D, 1e-5f, st, &ctx->err));
     GemmArgs ah = linear_args(ctx->hs, D, M, D, ctx->P("action_head.weight"), g.action_dim, ctx->P("action_head.bias"),
                               a_hat, g.action_dim);
-    CHK(launch_gemm(ah, st, &ctx->err));
+    CHK(ctx_gemm(ctx, ah, st));
     ctx->dbg["hs"] = {ctx->hs, (int64_t)M * D};
     return 0;
 }

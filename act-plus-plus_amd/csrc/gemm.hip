@@ -19,6 +19,7 @@
 // Planes are padded by one float4 so that the lanes writing one row's chunks hit different bank groups.
 #include "common.h"
 #include "dropout.h"
+#include "split16.h"
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -31,19 +32,36 @@ constexpr int NPL = BK / 4;
 enum { A_N = 0, A_CONV = 1, A_DGRAD = 2, A_T = 3, A_NADD = 4 };   // A_NADD: A_N with the broadcast addend
 enum { B_N = 0, B_T = 1, B_WGRAD = 2 };
 
-template <int BM, int BN>
-constexpr int stage_f4() { return NPL * ((BM + 1) + (BN + 1)); }
+// PREC: how an fp32 product is formed.
+//   PREC_F32   v_mfma_f32_32x32x2_f32, the native fp32 matrix instruction (157 TFLOP/s dense on MI355X)
+//   PREC_F16X3 each fp32 operand x is split EXACTLY into two fp16 pieces, hi = rn16(x), lo = rn16(x - hi) (together 22-23
+//              significand bits; fp16 subnormals are kept by gfx950's conversions and MFMA), and a*b is taken as
+//              hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation.  The dropped lo*lo term is
+//              2^-22 relative -- below the fp32 accumulation noise of a K >= 64 dot product -- so results are fp32-grade
+//              (measured: same |a_hat - reference| as PREC_F32), while the fp16 pipe is 16x wider: 3 products still
+//              leave 5.3x the native fp32 MFMA rate.  Operands must be finite and |x| < 65504.
+enum { PREC_F32 = 0, PREC_F16X3 = 1 };
+constexpr int ACTMI_PREC_DEFAULT_IS = ACTMI_PREC_F32;      // library default when neither descriptor nor environment says
+
+template <int BM, int BN, int PREC>
+constexpr int stage_f4() { return NPL * ((BM + (PREC ? 2 : 1)) + (BN + (PREC ? 2 : 1))); }
+
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;      // 256 threads (4 waves) or 512 (8 waves, 2 per SIMD) for the 256x128 tile
     constexpr int RPP = NT / 8;                          // rows staged per pass of the N-form loaders
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    constexpr int PSA = BM + 1, PSB = BN + 1;
-    constexpr int STAGE = stage_f4<BM, BN>();
+    // LDS plane stride in 16-byte units.  PREC_F16X3 re-uses the 8-plane stage: plane 2*kg holds the hi halves of
+    // contraction group kg (8 consecutive k), plane 2*kg+1 the lo halves; stride = 2 mod 8 keeps the 8-byte staging
+    // writes of a wave (4 groups x 2 halves x 4 rows per 256-byte bank sweep) conflict-free.
+    constexpr int PSA = BM + (PREC ? 2 : 1), PSB = BN + (PREC ? 2 : 1);
+    constexpr int STAGE = stage_f4<BM, BN, PREC>();
     constexpr int NLA = (AMODE == A_T) ? 4 : BM / RPP;
     constexpr int NLB = (BMODE != B_N) ? 4 : BN / RPP;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows staged per pass");
@@ -165,6 +183,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
         wg_s = rs - wg_r * p.KW;
     }
 
+    // block-uniform: every staged row and every k of every K tile is in range (no zero-fill needed)
+    const bool a_interior = m0 + BM <= p.M && (p.K % BK) == 0;
+    const bool b_interior = n0 + BN <= p.N && (p.K % BK) == 0;
     // staging registers of the K tile in flight
     struct Regs {
         f32x4 ra[NLA], rb[NLB], rx[AMODE == A_NADD ? NLA : 1];
@@ -292,6 +313,70 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     auto store_tile = [&](int stage, auto& R) {
         f32x4* sa = smem + stage * STAGE;
         f32x4* sb = sa + NPL * PSA;
+        if constexpr (PREC == PREC_F16X3) {
+            // a thread's float4 (4 consecutive k of one row) becomes 4 hi halfs + 4 lo halfs: two 8-byte stores into
+            // the (hi, lo) planes of its contraction group, at half (chunk & 1) of the 16-byte unit
+            uint2* sa8 = reinterpret_cast<uint2*>(sa);
+            uint2* sb8 = reinterpret_cast<uint2*>(sb);
+            if (AMODE == A_T) {
+                if (a_kg < NPL) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 v = {R.ra[0][i], R.ra[1][i], R.ra[2][i], R.ra[3][i]};
+                        uint2 hi, lo;
+                        split16(v, hi, lo);
+                        const int row = a_og * 4 + i;
+                        sa8[(((a_kg >> 1) * 2 + 0) * PSA + row) * 2 + (a_kg & 1)] = hi;
+                        sa8[(((a_kg >> 1) * 2 + 1) * PSA + row) * 2 + (a_kg & 1)] = lo;
+                    }
+                }
+            } else {
+                auto put_a = [&](auto masked) {
+#pragma unroll
+                    for (int i = 0; i < NLA; ++i) {
+                        f32x4 v = R.ra[i];
+                        if (AMODE == A_NADD) { if (use_add) v += R.rx[i]; }
+                        if (decltype(masked)::value && AMODE != A_DGRAD) v = R.ra_ok[i] ? v : zero4;
+                        uint2 hi, lo;
+                        split16(v, hi, lo);
+                        const int row = srow + RPP * i;
+                        sa8[(((cidx >> 1) * 2 + 0) * PSA + row) * 2 + (cidx & 1)] = hi;
+                        sa8[(((cidx >> 1) * 2 + 1) * PSA + row) * 2 + (cidx & 1)] = lo;
+                    }
+                };
+                // interior tiles of a plain row-major operand need no zero-fill selects (block-uniform branch)
+                if ((AMODE == A_N || AMODE == A_NADD) && a_interior) put_a(std::false_type{});
+                else put_a(std::true_type{});
+            }
+            if (BMODE == B_N) {
+#pragma unroll
+                for (int i = 0; i < NLB; ++i) {
+                    const f32x4 v = (b_interior || R.rb_ok[i]) ? R.rb[i] : zero4;
+                    uint2 hi, lo;
+                    if (p.b_split) {     // weights split ahead of time: each 16-byte group is {4 hi halfs, 4 lo halfs}
+                        const uint4 u = __builtin_bit_cast(uint4, v);
+                        hi = uint2{u.x, u.y};
+                        lo = uint2{u.z, u.w};
+                    } else split16(v, hi, lo);
+                    const int row = srow + RPP * i;
+                    sb8[(((cidx >> 1) * 2 + 0) * PSB + row) * 2 + (cidx & 1)] = hi;
+                    sb8[(((cidx >> 1) * 2 + 1) * PSB + row) * 2 + (cidx & 1)] = lo;
+                }
+            } else {
+                if (b_kg < NPL) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 v = {R.rb[0][i], R.rb[1][i], R.rb[2][i], R.rb[3][i]};
+                        uint2 hi, lo;
+                        split16(v, hi, lo);
+                        const int row = b_og * 4 + i;
+                        sb8[(((b_kg >> 1) * 2 + 0) * PSB + row) * 2 + (b_kg & 1)] = hi;
+                        sb8[(((b_kg >> 1) * 2 + 1) * PSB + row) * 2 + (b_kg & 1)] = lo;
+                    }
+                }
+            }
+            return;
+        }
         if (AMODE == A_T) {
             if (a_kg < NPL) {
 #pragma unroll
@@ -332,6 +417,63 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nsteps = kt_end - kt_begin;
+    if constexpr (PREC == PREC_F16X3) {
+        // fp16-split main loop.  A 32-deep K tile is only 24 MFMAs (768 pipe cycles) per wave here -- a fifth of the
+        // fp32 instruction's time -- so global loads run TWO tiles ahead of the MFMAs (two register stages), the LDS
+        // stage one tile ahead.
+        Regs R1;
+        load_tile(kt_begin, R0);
+        if (nsteps > 1) load_tile(kt_begin + 1, R1);
+        store_tile(0, R0);
+        __syncthreads();
+        auto compute16 = [&](int cur) {
+            const f32x4* sa = smem + cur * STAGE;
+            const f32x4* sb = sa + NPL * PSA;
+            f32x4 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int kg = 2 * s2 + lh;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[s2][i] = sa[(kg * 2 + 0) * PSA + wrow0 + i * 32 + li];
+                    al[s2][i] = sa[(kg * 2 + 1) * PSA + wrow0 + i * 32 + li];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[s2][j] = sb[(kg * 2 + 0) * PSB + wcol0 + j * 32 + li];
+                    bl[s2][j] = sb[(kg * 2 + 1) * PSB + wcol0 + j * 32 + li];
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const h16x8 xh = __builtin_bit_cast(h16x8, ah[s2][i]), xl = __builtin_bit_cast(h16x8, al[s2][i]);
+                        const h16x8 yh = __builtin_bit_cast(h16x8, bh[s2][j]), yl = __builtin_bit_cast(h16x8, bl[s2][j]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, acc[i][j], 0, 0, 0);
+                    }
+        };
+        int s_ = 0;
+        for (; s_ + 1 < nsteps; s_ += 2) {
+            // tile s_ is in LDS stage 0, tile s_+1 in flight in R1; R0 is free
+            if (s_ + 2 < nsteps) load_tile(kt_begin + s_ + 2, R0);
+            compute16(0);
+            store_tile(1, R1);
+            __syncthreads();
+            if (s_ + 3 < nsteps) load_tile(kt_begin + s_ + 3, R1);
+            compute16(1);
+            if (s_ + 2 < nsteps) store_tile(0, R0);
+            __syncthreads();
+        }
+        if (s_ < nsteps) {
+            compute16(0);
+            __syncthreads();
+        }
+    } else {
     load_tile(kt_begin, R0);
     store_tile(0, R0);
     __syncthreads();
@@ -403,6 +545,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     } else {
         kstep(s_, P0{}, std::false_type{});
     }
+    }   // PREC_F32
 
     if (stamp && threadIdx.x == 0) stamp[2] = __builtin_amdgcn_s_memtime();
     // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -509,12 +652,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     if (stamp && threadIdx.x == 0) stamp[3] = __builtin_amdgcn_s_memtime();
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC>
 int launch_cfg(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     static const int lds_pad = getenv("ACTMI_GEMM_LDSPAD") ? atoi(getenv("ACTMI_GEMM_LDSPAD")) : 0;   // tuning aid
-    const int smem = 2 * stage_f4<BM, BN>() * 16 + lds_pad;
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AMODE, BMODE>;
+    const int smem = 2 * stage_f4<BM, BN, PREC>() * 16 + lds_pad;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AMODE, BMODE, PREC>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -526,7 +669,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t st) {
     dim3 grid(tiles_m * tiles_n, 1, (a.groups > 0 ? a.groups : 1) * splitk);
     if (prof_enabled()) {
         char nm[64];
-        snprintf(nm, sizeof(nm), "gemm_f32_kernel<%d,%d,%d,%d,%d,%d>", BM, BN, WM, WN, AMODE, BMODE);
+        snprintf(nm, sizeof(nm), "gemm_%s_kernel<%d,%d,%d,%d,%d,%d>", PREC ? "f16x3" : "f32", BM, BN, WM, WN, AMODE, BMODE);
         const double g = a.groups;
         double abytes;
         if (AMODE == A_CONV) abytes = (double)(a.M / (a.Ho * a.Wo)) * a.H * a.W * a.Cin;
@@ -547,19 +690,21 @@ double tile_eff(int M, int N, int nz, int BM, int BN, double factor) {
     return factor * ((double)M * N * nz) / ((double)rounds * 256 * BM * BN);
 }
 
-template <int AMODE, int BMODE>
+template <int AMODE, int BMODE, int PREC>
 int launch_modes(const GemmArgs& a, hipStream_t st) {
     const int nz = (a.groups > 0 ? a.groups : 1) * (a.splitk > 1 ? a.splitk : 1);
+    // relative speed of the tile shapes at equal occupancy (measured on the ACT shapes): the fp16-split loop spends 5x
+    // fewer MFMA cycles per staged byte, so small tiles (more L2 traffic per FLOP) cost it more
     const double eL = tile_eff(a.M, a.N, nz, 128, 128, 1.00);
-    const double eM = tile_eff(a.M, a.N, nz, 128, 64, 0.95);
-    const double eS = tile_eff(a.M, a.N, nz, 64, 64, 0.88);
+    const double eM = tile_eff(a.M, a.N, nz, 128, 64, PREC ? 0.80 : 0.95);
+    const double eS = tile_eff(a.M, a.N, nz, 64, 64, PREC ? 0.78 : 0.88);
     static const char* force = getenv("ACTMI_GEMM_CFG");      // tuning aid: L / M / S
-    if (force && force[0] == 'L') return launch_cfg<128, 128, 64, 64, AMODE, BMODE>(a, st);
-    if (force && force[0] == 'M') return launch_cfg<128, 64, 64, 32, AMODE, BMODE>(a, st);
-    if (force && force[0] == 'S') return launch_cfg<64, 64, 32, 32, AMODE, BMODE>(a, st);
-    if (eL >= eM && eL >= eS) return launch_cfg<128, 128, 64, 64, AMODE, BMODE>(a, st);
-    if (eM >= eS) return launch_cfg<128, 64, 64, 32, AMODE, BMODE>(a, st);
-    return launch_cfg<64, 64, 32, 32, AMODE, BMODE>(a, st);
+    if (force && force[0] == 'L') return launch_cfg<128, 128, 64, 64, AMODE, BMODE, PREC>(a, st);
+    if (force && force[0] == 'M') return launch_cfg<128, 64, 64, 32, AMODE, BMODE, PREC>(a, st);
+    if (force && force[0] == 'S') return launch_cfg<64, 64, 32, 32, AMODE, BMODE, PREC>(a, st);
+    if (eL >= eM && eL >= eS) return launch_cfg<128, 128, 64, 64, AMODE, BMODE, PREC>(a, st);
+    if (eM >= eS) return launch_cfg<128, 64, 64, 32, AMODE, BMODE, PREC>(a, st);
+    return launch_cfg<64, 64, 32, 32, AMODE, BMODE, PREC>(a, st);
 }
 
 }  // namespace
@@ -611,15 +756,27 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t st, std::string* err) {
         if (!a.ta) return fail("wgrad: A (dY) must be given in [m][n] storage (ta=1)");
     } else return fail("bad tb");
     int rc;
-    if (amode == A_N && bmode == B_N && a.A_add) rc = launch_modes<A_NADD, B_N>(a, st);
-    else if (amode == A_N && bmode == B_N) rc = launch_modes<A_N, B_N>(a, st);
-    else if (amode == A_CONV && bmode == B_N) rc = launch_modes<A_CONV, B_N>(a, st);
-    else if (amode == A_DGRAD && bmode == B_N) rc = launch_modes<A_DGRAD, B_N>(a, st);
-    else if (amode == A_N && bmode == B_T) rc = launch_modes<A_N, B_T>(a, st);
-    else if (amode == A_T && bmode == B_T) rc = launch_modes<A_T, B_T>(a, st);
-    else if (amode == A_T && bmode == B_WGRAD) rc = launch_modes<A_T, B_WGRAD>(a, st);
-    else if (amode == A_T && bmode == B_N) rc = launch_modes<A_T, B_N>(a, st);
+    // precision: explicit in the descriptor, else ACTMI_GEMM_PREC (f32 | f16x3), else the library default
+    static const int env_prec = [] {
+        const char* e = getenv("ACTMI_GEMM_PREC");
+        if (!e) return ACTMI_PREC_DEFAULT_IS;
+        return (e[0] == 'f' && e[1] == '3') ? ACTMI_PREC_F32 : ACTMI_PREC_F16X3;
+    }();
+    const int prec = a.prec ? a.prec : env_prec;
+    if (prec != ACTMI_PREC_F32 && prec != ACTMI_PREC_F16X3) return fail("bad prec");
+    if (a.b_split && (prec != ACTMI_PREC_F16X3 || bmode != B_N)) return fail("b_split needs prec f16x3 and a contraction-contiguous B");
+#define ACTMI_DISPATCH(PREC)                                                                                       \
+    if (amode == A_N && bmode == B_N && a.A_add) rc = launch_modes<A_NADD, B_N, PREC>(a, st);                      \
+    else if (amode == A_N && bmode == B_N) rc = launch_modes<A_N, B_N, PREC>(a, st);                               \
+    else if (amode == A_CONV && bmode == B_N) rc = launch_modes<A_CONV, B_N, PREC>(a, st);                         \
+    else if (amode == A_DGRAD && bmode == B_N) rc = launch_modes<A_DGRAD, B_N, PREC>(a, st);                       \
+    else if (amode == A_N && bmode == B_T) rc = launch_modes<A_N, B_T, PREC>(a, st);                               \
+    else if (amode == A_T && bmode == B_T) rc = launch_modes<A_T, B_T, PREC>(a, st);                               \
+    else if (amode == A_T && bmode == B_WGRAD) rc = launch_modes<A_T, B_WGRAD, PREC>(a, st);                       \
+    else if (amode == A_T && bmode == B_N) rc = launch_modes<A_T, B_N, PREC>(a, st);                               \
     else return fail("operand form combination not instantiated");
+    if (prec == ACTMI_PREC_F16X3) { ACTMI_DISPATCH(PREC_F16X3) } else { ACTMI_DISPATCH(PREC_F32) }
+#undef ACTMI_DISPATCH
     if (rc != 0 && err) *err = std::string("gemm launch: ") + hipGetErrorString((hipError_t)rc);
     return rc == 0 ? 0 : -3;
 }

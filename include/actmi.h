@@ -52,6 +52,9 @@ typedef struct actmi_config {
  * C[rowmap(m)][n] = act((sum_k A'[m][k] * Bw[n][k]) * scale[n] + bias[n] + res[m % res_mod][n]).
  * Replaces ATen addmm / cuDNN convolution as launched by nn.Linear, nn.MultiheadAttention projections and
  * torchvision Conv2d+FrozenBatchNorm2d (backbone.py:47-57). */
+#define ACTMI_PREC_F32 1
+#define ACTMI_PREC_F16X3 2
+
 typedef struct actmi_gemm_desc {
     const float* A;
     int64_t lda;
@@ -103,6 +106,13 @@ typedef struct actmi_gemm_desc {
     /* diagnostic: when non-NULL, thread 0 of every block writes 4 shader-clock stamps (s_memtime) here:
      * [block][0] entry, [1] first LDS stage ready, [2] K loop done, [3] epilogue done.  Never set on the product path. */
     uint64_t* stamps;
+    /* how each fp32 product is formed: 0 = default (environment ACTMI_GEMM_PREC=f32|f16x3, else the library default),
+     * ACTMI_PREC_F32 = native fp32 MFMA, ACTMI_PREC_F16X3 = exact two-piece fp16 split of both operands, three fp16
+     * MFMA products, fp32 accumulation (fp32-grade results, needs finite |x| < 65504) */
+    int32_t prec;
+    /* f16x3 only: Bw already holds split weights (actmi_op_split16: every aligned group of 4 floats replaced by
+     * 4 hi halfs + 4 lo halfs, same addressing as the fp32 matrix) */
+    int32_t b_split;
 } actmi_gemm_desc;
 
 /* Multi-head attention descriptor: softmax(scale * q k^T [+ key padding mask]) v per (batch, head).
@@ -171,6 +181,8 @@ int actmi_ensemble_step(float* ring, int32_t* tcount, const float* chunk, double
 
 /* ---- kernel-level entry points (unit tests, external callers) --------------------------------------- */
 int actmi_op_gemm(const actmi_gemm_desc* d, void* stream);
+/* weight preparation for actmi_gemm_desc.b_split: dst = fp16-split image of src (device pointers, may not alias) */
+int actmi_op_split16(const float* src, float* dst, int64_t nfloats, void* stream);
 int actmi_op_attention(const actmi_attn_desc* d, void* stream);
 int actmi_op_layernorm(const float* x, const float* res, int res_mod, const float* w, const float* b, const float* w2,
                        const float* b2, float* y, int M, int D, float eps, void* stream);

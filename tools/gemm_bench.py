@@ -8,6 +8,7 @@ from actmi import ops
 
 dev = torch.device("cuda:0")
 VENDOR = os.environ.get("GEMM_BENCH_VENDOR") == "1"
+SPLITW = os.environ.get("GEMM_BENCH_SPLITW") == "1"     # weights pre-split (needs ACTMI_GEMM_PREC=f16x3)
 torch.backends.cuda.matmul.allow_tf32 = False
 
 def timeit(fn, iters=20):
@@ -22,7 +23,8 @@ def timeit(fn, iters=20):
 def lin(M, N, K, tag):
     A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
     out = torch.empty(M, N, device=dev)
-    ms = timeit(lambda: ops.gemm(A, W, bias=b, out=out))
+    if SPLITW: W = ops.split16(W)
+    ms = timeit(lambda: ops.gemm(A, W, bias=b, out=out, w_split=SPLITW))
     line = f"{tag:28s} M={M:6d} N={N:5d} K={K:5d}  {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TF"
     if VENDOR:      # the vendor library (rocBLAS / hipBLASLt behind torch.addmm), same shape, for orientation only
         ms2 = timeit(lambda: torch.addmm(b, A, W.t(), out=out))
@@ -33,7 +35,8 @@ def conv(G, B, H, W_, Cin, Cout, k, s, p, tag):
     x = torch.randn(G, B, H, W_, Cin, device=dev); w = torch.randn(G, Cout, k, k, Cin, device=dev)
     sc = torch.rand(G, Cout, device=dev); bi = torch.rand(G, Cout, device=dev)
     Ho, Wo = (H + 2*p - k)//s + 1, (W_ + 2*p - k)//s + 1
-    ms = timeit(lambda: ops.conv2d_nhwc(x, w, sc, bi, None, True, s, p))
+    if SPLITW: w = ops.split16(w)
+    ms = timeit(lambda: ops.conv2d_nhwc(x, w, sc, bi, None, True, s, p, w_split=SPLITW))
     fl = 2.0 * G * B * Ho * Wo * Cout * k * k * Cin
     print(f"{tag:28s} M={B*Ho*Wo:6d} N={Cout:5d} K={k*k*Cin:5d}  {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF")
 
