@@ -16,7 +16,10 @@ from .weights import act_state_dict_spec, is_buffer
 
 
 class ACTEngine:
-    def __init__(self, cfg: ACTConfig, max_batch: int = 8, device: str = "cuda:0", training: bool = False):
+    def __init__(self, cfg: ACTConfig, max_batch: int = 8, device: str = "cuda:0", training: bool = False,
+                 gemm_prec: str = None):
+        """gemm_prec: "f16x3" (default; fp32 products formed from three fp16 MFMA products of exactly split operands,
+        fp32-grade results) or "f32" (native fp32 MFMA); None = environment ACTMI_GEMM_PREC or the default."""
         if not torch.cuda.is_available():
             raise RuntimeError("ACTEngine needs an MI355X (torch.cuda.is_available() is False); no CPU fallback exists")
         self.cfg = cfg.validate()
@@ -35,6 +38,8 @@ class ACTEngine:
         if rc != 0:
             raise RuntimeError(f"actmi_create failed ({rc}): {self.lib.actmi_last_error(None).decode()}")
         self.h = h
+        if gemm_prec is not None:
+            L.check(self.lib.actmi_set_gemm_prec(self.h, {"f32": 1, "f16x3": 2}[gemm_prec]), self.h, "set_gemm_prec")
         self.spec = act_state_dict_spec(cfg)
         self._finalized = False
         # attributes imitate_episodes.py touches on policy.model

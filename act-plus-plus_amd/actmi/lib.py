@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
         ("alpha", C.c_float), ("groups_inner", C.c_int32),
         ("gA2", C.c_int64), ("gB2", C.c_int64), ("gC2", C.c_int64), ("gRes2", C.c_int64),
         ("gMask", C.c_int64), ("gC2out", C.c_int64),
-        ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("stamps", C.c_void_p), ("prec", C.c_int32), ("b_split", C.c_int32),
+        ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("stamps", C.c_void_p), ("prec", C.c_int32), ("b_split", C.c_int32), ("b_scale", C.c_float),
     ]
 
 
@@ -92,7 +92,7 @@ def load():
         "actmi_grad_arena": ([vp, C.POINTER(vp), C.POINTER(i64)], i32),
         "actmi_ensemble_step": ([vp, vp, vp, f64, vp, vp, i32, i32, i32, vp], i32),
         "actmi_op_gemm": ([C.POINTER(GemmDesc), vp], i32),
-        "actmi_op_split16": ([vp, vp, C.c_int64, vp], i32),
+        "actmi_op_split16": ([vp, vp, C.c_int64, C.c_float, vp], i32),
         "actmi_op_attention": ([C.POINTER(AttnDesc), vp], i32),
         "actmi_op_layernorm": ([vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp], i32),
         "actmi_op_maxpool3x3s2": ([vp, vp, i32, i32, i32, i32, vp], i32),
@@ -100,6 +100,7 @@ def load():
         "actmi_op_last_error": ([], C.c_char_p),
         "actmi_debug_tensor": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i64)], i32),
         "actmi_debug_stop_after": ([vp, C.c_char_p], i32),
+        "actmi_set_gemm_prec": ([vp, i32], i32),
         "actmi_profile_enable": ([i32], i32),
         "actmi_profile_reset": ([], i32),
         "actmi_profile_report": ([C.c_char_p, i32], i32),

@@ -13,12 +13,13 @@ def _p(t):
 PREC = {None: 0, "f32": 1, "f16x3": 2}
 
 
-def split16(w):
-    """fp16-split image of an f32 cuda tensor (numel % 4 == 0): what `gemm(..., prec="f16x3", w_split=True)` consumes."""
+def split16(w, scale=1.0):
+    """fp16-split image of (an f32 cuda tensor * scale), numel % 4 == 0: what `gemm(..., prec="f16x3", w_split=scale)`
+    consumes; scale is a power of two."""
     lib = L.load()
     w = w.contiguous()
     out = torch.empty_like(w)
-    L.check(lib.actmi_op_split16(_p(w), _p(out), w.numel(), L.current_stream_ptr()), None, "op_split16")
+    L.check(lib.actmi_op_split16(_p(w), _p(out), w.numel(), float(scale), L.current_stream_ptr()), None, "op_split16")
     return out
 
 
@@ -44,7 +45,7 @@ def gemm(A, W, bias=None, scale=None, res=None, res_mod=0, relu=False, a_add=Non
     d.rowmap = rowmap.data_ptr() if rowmap is not None else None
     d.M, d.N, d.K, d.groups = M, N, K, 1
     d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)
-    d.prec, d.b_split = PREC[prec], 1 if w_split else 0
+    d.prec, d.b_split, d.b_scale = PREC[prec], 1 if w_split else 0, float(w_split)
     L.check(lib.actmi_op_gemm(C.byref(d), L.current_stream_ptr()), None, "op_gemm")
     return out
 
@@ -70,7 +71,7 @@ def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1
     d.M, d.N, d.K, d.groups = B * Ho * Wo, Cout, KH * KW * Cin, G
     d.gA, d.gB, d.gSB = B * H * W * Cin, Cout * KH * KW * Cin, Cout
     d.gC = d.gRes = B * Ho * Wo * Cout
-    d.prec, d.b_split = PREC[prec], 1 if w_split else 0
+    d.prec, d.b_split, d.b_scale = PREC[prec], 1 if w_split else 0, float(w_split)
     L.check(lib.actmi_op_gemm(C.byref(d), L.current_stream_ptr()), None, "op_gemm(conv)")
     return out
 

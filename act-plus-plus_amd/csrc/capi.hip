@@ -119,9 +119,9 @@ int actmi_op_gemm(const actmi_gemm_desc* d, void* stream) {
     return launch_gemm(*d, S(stream), &g_op_error);
 }
 
-int actmi_op_split16(const float* src, float* dst, int64_t nfloats, void* stream) {
+int actmi_op_split16(const float* src, float* dst, int64_t nfloats, float scale, void* stream) {
     g_op_error.clear();
-    const int rc = launch_split16(src, dst, nfloats, S(stream));
+    const int rc = launch_split16(src, dst, nfloats, scale, S(stream));
     if (rc != 0) g_op_error = "split16: nfloats must be a multiple of 4 and both pointers 16-byte aligned";
     return rc == 0 ? 0 : ACTMI_E_INVALID;
 }
@@ -162,6 +162,14 @@ int actmi_op_conv1(const void* image, int image_fmt, const float* w_oihw, const 
 }
 
 const char* actmi_op_last_error(void) { return g_op_error.c_str(); }
+
+int actmi_set_gemm_prec(actmi_handle h, int prec) {
+    if (!h) return ACTMI_E_INVALID;
+    if (prec != ACTMI_PREC_F32 && prec != ACTMI_PREC_F16X3) { h->err = "prec must be ACTMI_PREC_F32 or ACTMI_PREC_F16X3"; return ACTMI_E_INVALID; }
+    h->gemm_prec = prec;
+    h->finalized = false;
+    return 0;
+}
 
 int actmi_debug_stop_after(actmi_handle h, const char* stage) {
     if (!h) return ACTMI_E_INVALID;

@@ -151,6 +151,9 @@ int dev_alloc(actmi_ctx* ctx, float** p, int64_t nfloats) {
 
 }  // namespace
 
+// the split weight image holds W * 2^8: the lo pieces of weights around 1e-2 stay normal fp16 numbers; |W| < 255 assumed
+static constexpr float W16_SCALE = 256.f;
+
 int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
     a.prec = ctx->gemm_prec;
     if (ctx->gemm_prec == ACTMI_PREC_F16X3 && a.tb == 0) {
@@ -158,9 +161,10 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
         if (a.Bw >= ctx->pbase && a.Bw < ctx->pbase + ctx->ptotal) {
             a.Bw = ctx->p16base + (a.Bw - ctx->pbase);
             a.b_split = 1;
+            a.b_scale = W16_SCALE;
         } else {
             for (const ConvLayer& cl : ctx->convs)
-                if (a.Bw == cl.w) { a.Bw = cl.w16; a.b_split = 1; break; }
+                if (a.Bw == cl.w) { a.Bw = cl.w16; a.b_split = 1; a.b_scale = W16_SCALE; break; }
         }
     }
     return launch_gemm(a, st, &ctx->err);
@@ -371,9 +375,9 @@ int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st) {
         }
     }
     if (ctx->gemm_prec == ACTMI_PREC_F16X3) {
-        CHK(launch_split16(ctx->pbase, ctx->p16base, ctx->ptotal, st));
+        CHK(launch_split16(ctx->pbase, ctx->p16base, ctx->ptotal, W16_SCALE, st));
         for (const ConvLayer& cl : ctx->convs)
-            CHK(launch_split16(cl.w, cl.w16, (int64_t)C * cl.cout * cl.K, st));
+            CHK(launch_split16(cl.w, cl.w16, (int64_t)C * cl.cout * cl.K, W16_SCALE, st));
     }
     // learned rows of the token position table (transformer.py:91-92)
     HIPCHK(hipMemcpyAsync(ctx->pos_tokens, ctx->P("additional_pos_embed.weight"), 2 * D * sizeof(float),

@@ -51,7 +51,7 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC>
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC, int BSPLIT>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;      // 256 threads (4 waves) or 512 (8 waves, 2 per SIMD) for the 256x128 tile
     constexpr int RPP = NT / 8;                          // rows staged per pass of the N-form loaders
@@ -183,9 +183,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
         wg_s = rs - wg_r * p.KW;
     }
 
-    // block-uniform: every staged row and every k of every K tile is in range (no zero-fill needed)
-    const bool a_interior = m0 + BM <= p.M && (p.K % BK) == 0;
-    const bool b_interior = n0 + BN <= p.N && (p.K % BK) == 0;
     // staging registers of the K tile in flight
     struct Regs {
         f32x4 ra[NLA], rb[NLB], rx[AMODE == A_NADD ? NLA : 1];
@@ -310,73 +307,72 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
             }
         }
     };
+    // fp16-split staging: a thread's float4 (4 consecutive k of one row) becomes 4 hi halfs + 4 lo halfs -- two 8-byte
+    // stores into the (hi, lo) planes of its contraction group, at half (chunk & 1) of the 16-byte unit.
+    // MASKED = false: no zero-fill selects (legal when K is a multiple of the K tile and the operand is plain row-major:
+    // rows beyond M / N are staged from a valid clamped address and only ever reach outputs that are not stored).
+    auto store16 = [&](int stage, auto& R, auto maskedc) {
+        constexpr bool MASKED = decltype(maskedc)::value;
+        f32x4* sa = smem + stage * STAGE;
+        f32x4* sb = sa + NPL * PSA;
+        uint2* sa8 = reinterpret_cast<uint2*>(sa);
+        uint2* sb8 = reinterpret_cast<uint2*>(sb);
+        if (AMODE == A_T) {
+            if (a_kg < NPL) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 v = {R.ra[0][i], R.ra[1][i], R.ra[2][i], R.ra[3][i]};
+                    uint2 hi, lo;
+                    split16(v, hi, lo);
+                    const int row = a_og * 4 + i;
+                    sa8[(((a_kg >> 1) * 2 + 0) * PSA + row) * 2 + (a_kg & 1)] = hi;
+                    sa8[(((a_kg >> 1) * 2 + 1) * PSA + row) * 2 + (a_kg & 1)] = lo;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) {
+                f32x4 v = R.ra[i];
+                if (AMODE == A_NADD) { if (use_add) v += R.rx[i]; }
+                if (AMODE == A_CONV || (MASKED && AMODE != A_DGRAD)) v = R.ra_ok[i] ? v : zero4;
+                uint2 hi, lo;
+                split16(v, hi, lo);
+                const int row = srow + RPP * i;
+                sa8[(((cidx >> 1) * 2 + 0) * PSA + row) * 2 + (cidx & 1)] = hi;
+                sa8[(((cidx >> 1) * 2 + 1) * PSA + row) * 2 + (cidx & 1)] = lo;
+            }
+        }
+        if (BMODE == B_N) {
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) {
+                const f32x4 v = (!MASKED || R.rb_ok[i]) ? R.rb[i] : zero4;
+                uint2 hi, lo;
+                if (BSPLIT) {     // weights split ahead of time: each 16-byte group is {4 hi halfs, 4 lo halfs}
+                    const uint4 u = __builtin_bit_cast(uint4, v);
+                    hi = uint2{u.x, u.y};
+                    lo = uint2{u.z, u.w};
+                } else split16(v, hi, lo);
+                const int row = srow + RPP * i;
+                sb8[(((cidx >> 1) * 2 + 0) * PSB + row) * 2 + (cidx & 1)] = hi;
+                sb8[(((cidx >> 1) * 2 + 1) * PSB + row) * 2 + (cidx & 1)] = lo;
+            }
+        } else {
+            if (b_kg < NPL) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 v = {R.rb[0][i], R.rb[1][i], R.rb[2][i], R.rb[3][i]};
+                    uint2 hi, lo;
+                    split16(v, hi, lo);
+                    const int row = b_og * 4 + i;
+                    sb8[(((b_kg >> 1) * 2 + 0) * PSB + row) * 2 + (b_kg & 1)] = hi;
+                    sb8[(((b_kg >> 1) * 2 + 1) * PSB + row) * 2 + (b_kg & 1)] = lo;
+                }
+            }
+        }
+    };
     auto store_tile = [&](int stage, auto& R) {
         f32x4* sa = smem + stage * STAGE;
         f32x4* sb = sa + NPL * PSA;
-        if constexpr (PREC == PREC_F16X3) {
-            // a thread's float4 (4 consecutive k of one row) becomes 4 hi halfs + 4 lo halfs: two 8-byte stores into
-            // the (hi, lo) planes of its contraction group, at half (chunk & 1) of the 16-byte unit
-            uint2* sa8 = reinterpret_cast<uint2*>(sa);
-            uint2* sb8 = reinterpret_cast<uint2*>(sb);
-            if (AMODE == A_T) {
-                if (a_kg < NPL) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const f32x4 v = {R.ra[0][i], R.ra[1][i], R.ra[2][i], R.ra[3][i]};
-                        uint2 hi, lo;
-                        split16(v, hi, lo);
-                        const int row = a_og * 4 + i;
-                        sa8[(((a_kg >> 1) * 2 + 0) * PSA + row) * 2 + (a_kg & 1)] = hi;
-                        sa8[(((a_kg >> 1) * 2 + 1) * PSA + row) * 2 + (a_kg & 1)] = lo;
-                    }
-                }
-            } else {
-                auto put_a = [&](auto masked) {
-#pragma unroll
-                    for (int i = 0; i < NLA; ++i) {
-                        f32x4 v = R.ra[i];
-                        if (AMODE == A_NADD) { if (use_add) v += R.rx[i]; }
-                        if (decltype(masked)::value && AMODE != A_DGRAD) v = R.ra_ok[i] ? v : zero4;
-                        uint2 hi, lo;
-                        split16(v, hi, lo);
-                        const int row = srow + RPP * i;
-                        sa8[(((cidx >> 1) * 2 + 0) * PSA + row) * 2 + (cidx & 1)] = hi;
-                        sa8[(((cidx >> 1) * 2 + 1) * PSA + row) * 2 + (cidx & 1)] = lo;
-                    }
-                };
-                // interior tiles of a plain row-major operand need no zero-fill selects (block-uniform branch)
-                if ((AMODE == A_N || AMODE == A_NADD) && a_interior) put_a(std::false_type{});
-                else put_a(std::true_type{});
-            }
-            if (BMODE == B_N) {
-#pragma unroll
-                for (int i = 0; i < NLB; ++i) {
-                    const f32x4 v = (b_interior || R.rb_ok[i]) ? R.rb[i] : zero4;
-                    uint2 hi, lo;
-                    if (p.b_split) {     // weights split ahead of time: each 16-byte group is {4 hi halfs, 4 lo halfs}
-                        const uint4 u = __builtin_bit_cast(uint4, v);
-                        hi = uint2{u.x, u.y};
-                        lo = uint2{u.z, u.w};
-                    } else split16(v, hi, lo);
-                    const int row = srow + RPP * i;
-                    sb8[(((cidx >> 1) * 2 + 0) * PSB + row) * 2 + (cidx & 1)] = hi;
-                    sb8[(((cidx >> 1) * 2 + 1) * PSB + row) * 2 + (cidx & 1)] = lo;
-                }
-            } else {
-                if (b_kg < NPL) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const f32x4 v = {R.rb[0][i], R.rb[1][i], R.rb[2][i], R.rb[3][i]};
-                        uint2 hi, lo;
-                        split16(v, hi, lo);
-                        const int row = b_og * 4 + i;
-                        sb8[(((b_kg >> 1) * 2 + 0) * PSB + row) * 2 + (b_kg & 1)] = hi;
-                        sb8[(((b_kg >> 1) * 2 + 1) * PSB + row) * 2 + (b_kg & 1)] = lo;
-                    }
-                }
-            }
-            return;
-        }
         if (AMODE == A_T) {
             if (a_kg < NPL) {
 #pragma unroll
@@ -420,12 +416,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     if constexpr (PREC == PREC_F16X3) {
         // fp16-split main loop.  A 32-deep K tile is only 24 MFMAs (768 pipe cycles) per wave here -- a fifth of the
         // fp32 instruction's time -- so global loads run TWO tiles ahead of the MFMAs (two register stages), the LDS
-        // stage one tile ahead.
-        Regs R1;
-        load_tile(kt_begin, R0);
-        if (nsteps > 1) load_tile(kt_begin + 1, R1);
-        store_tile(0, R0);
-        __syncthreads();
+        // stage one tile ahead, and the loop body is kept ONE basic block (tail loads are clamped to the last tile
+        // instead of branched around; a surplus stage store is harmless) so that the scheduler can weave the next
+        // tile's conversions and LDS traffic between the MFMAs.
         auto compute16 = [&](int cur) {
             const f32x4* sa = smem + cur * STAGE;
             const f32x4* sb = sa + NPL * PSA;
@@ -457,22 +450,49 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, acc[i][j], 0, 0, 0);
                     }
         };
-        int s_ = 0;
-        for (; s_ + 1 < nsteps; s_ += 2) {
-            // tile s_ is in LDS stage 0, tile s_+1 in flight in R1; R0 is free
-            if (s_ + 2 < nsteps) load_tile(kt_begin + s_ + 2, R0);
-            compute16(0);
-            store_tile(1, R1);
+        auto run = [&](auto maskedc) {
+            Regs R1;
+            const int kt_last = kt_end - 1;
+            auto ld = [&](int kt, auto& R) { load_tile(kt < kt_last ? kt : kt_last, R); };
+            constexpr bool HOT = (AMODE == A_N || AMODE == A_NADD || AMODE == A_CONV) && BMODE == B_N;
+            auto weave = [&]() {
+                // per MFMA: a few conversion / address VALU ops, one LDS access and one global load of the tiles ahead
+                if (HOT) {
+#pragma unroll
+                    for (int r = 0; r < 6 * TM * TN; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+            };
+            ld(kt_begin, R0);
+            ld(kt_begin + 1, R1);
+            store16(0, R0, maskedc);
             __syncthreads();
-            if (s_ + 3 < nsteps) load_tile(kt_begin + s_ + 3, R1);
-            compute16(1);
-            if (s_ + 2 < nsteps) store_tile(0, R0);
-            __syncthreads();
-        }
-        if (s_ < nsteps) {
-            compute16(0);
-            __syncthreads();
-        }
+            int s_ = 0;
+            for (; s_ + 1 < nsteps; s_ += 2) {
+                // tile s_ is in LDS stage 0, tile s_+1 in flight in R1; R0 is free
+                ld(kt_begin + s_ + 2, R0);
+                compute16(0);
+                store16(1, R1, maskedc);
+                weave();
+                __syncthreads();
+                ld(kt_begin + s_ + 3, R1);
+                compute16(1);
+                store16(0, R0, maskedc);
+                weave();
+                __syncthreads();
+            }
+            if (s_ < nsteps) {
+                compute16(0);
+                __syncthreads();
+            }
+        };
+        // block-uniform choice of the loop flavour
+        if ((AMODE == A_N || AMODE == A_NADD || AMODE == A_CONV) && BMODE == B_N && (p.K % BK) == 0) run(std::false_type{});
+        else run(std::true_type{});
     } else {
     load_tile(kt_begin, R0);
     store_tile(0, R0);
@@ -556,7 +576,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     const int64_t ldmask = p.ldmask ? p.ldmask : p.ldc;
     float* C = p.C + offC;
     float* C2 = p.C2 ? p.C2 + (int64_t)g * p.gC2out : nullptr;
-    const float alpha = p.alpha != 0.f ? p.alpha : 1.f;
+    // a pre-split B image may carry a power-of-two scale (keeps small weights' lo pieces out of fp16 subnormals)
+    const float alpha = (p.alpha != 0.f ? p.alpha : 1.f) * ((BSPLIT && p.b_scale != 0.f) ? 1.f / p.b_scale : 1.f);
     const bool has_res = res != nullptr, has_mask = mask != nullptr, has_map = p.rowmap != nullptr;
     const float drop_scale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
     // Fast epilogue for the forward-pass cases (bias / FrozenBN affine, optional same-shape residual, optional ReLU): the
@@ -652,12 +673,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     if (stamp && threadIdx.x == 0) stamp[3] = __builtin_amdgcn_s_memtime();
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC>
-int launch_cfg(const GemmArgs& a, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC, int BSPLIT>
+int launch_cfg_b(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     static const int lds_pad = getenv("ACTMI_GEMM_LDSPAD") ? atoi(getenv("ACTMI_GEMM_LDSPAD")) : 0;   // tuning aid
     const int smem = 2 * stage_f4<BM, BN, PREC>() * 16 + lds_pad;
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AMODE, BMODE, PREC>;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -682,6 +703,16 @@ int launch_cfg(const GemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, dim3((BM / WM) * (BN / WN) * 64), smem, st, a, tiles_m, tiles_n);
     prof_end(st);
     return (int)hipGetLastError();
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC>
+int launch_cfg(const GemmArgs& a, hipStream_t st) {
+    // pre-split weights exist only for the forward operand forms
+    constexpr bool CAN_BSPLIT = PREC == PREC_F16X3 && BMODE == B_N && (AMODE == A_N || AMODE == A_NADD || AMODE == A_CONV);
+    if constexpr (CAN_BSPLIT) {
+        if (a.b_split) return launch_cfg_b<BM, BN, WM, WN, AMODE, BMODE, PREC, 1>(a, st);
+    }
+    return launch_cfg_b<BM, BN, WM, WN, AMODE, BMODE, PREC, 0>(a, st);
 }
 
 double tile_eff(int M, int N, int nz, int BM, int BN, double factor) {
@@ -764,7 +795,8 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t st, std::string* err) {
     }();
     const int prec = a.prec ? a.prec : env_prec;
     if (prec != ACTMI_PREC_F32 && prec != ACTMI_PREC_F16X3) return fail("bad prec");
-    if (a.b_split && (prec != ACTMI_PREC_F16X3 || bmode != B_N)) return fail("b_split needs prec f16x3 and a contraction-contiguous B");
+    if (a.b_split && (prec != ACTMI_PREC_F16X3 || bmode != B_N || !(amode == A_N || amode == A_CONV)))
+        return fail("b_split needs prec f16x3 and the forward operand forms");
 #define ACTMI_DISPATCH(PREC)                                                                                       \
     if (amode == A_N && bmode == B_N && a.A_add) rc = launch_modes<A_NADD, B_N, PREC>(a, st);                      \
     else if (amode == A_N && bmode == B_N) rc = launch_modes<A_N, B_N, PREC>(a, st);                               \

@@ -224,20 +224,20 @@ int launch_bcast_add_rows(float* dst, const float* vec, int R, int D, hipStream_
 }
 
 // weights for the f16x3 GEMM: every aligned group of 4 floats -> {4 hi halfs, 4 lo halfs} in the same 16 bytes
-__global__ void split16_kernel(const actmi_f32x4* __restrict__ src, uint4* __restrict__ dst, int64_t n4) {
+__global__ void split16_kernel(const actmi_f32x4* __restrict__ src, uint4* __restrict__ dst, int64_t n4, float scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     uint2 hi, lo;
-    split16(src[i], hi, lo);
+    split16(src[i] * scale, hi, lo);
     dst[i] = uint4{hi.x, hi.y, lo.x, lo.y};
 }
 
-int launch_split16(const float* src, float* dst, int64_t nfloats, hipStream_t st) {
+int launch_split16(const float* src, float* dst, int64_t nfloats, float scale, hipStream_t st) {
     if (nfloats <= 0) return 0;
     if ((nfloats & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return -2;
     const int64_t n4 = nfloats / 4;
     hipLaunchKernelGGL(split16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<const actmi_f32x4*>(src), reinterpret_cast<uint4*>(dst), n4);
+                       reinterpret_cast<const actmi_f32x4*>(src), reinterpret_cast<uint4*>(dst), n4, scale);
     return (int)hipGetLastError();
 }
 

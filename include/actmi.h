@@ -113,6 +113,8 @@ typedef struct actmi_gemm_desc {
     /* f16x3 only: Bw already holds split weights (actmi_op_split16: every aligned group of 4 floats replaced by
      * 4 hi halfs + 4 lo halfs, same addressing as the fp32 matrix) */
     int32_t b_split;
+    /* with b_split: the image was built from Bw * b_scale (a power of two, see actmi_op_split16); 0 means 1 */
+    float b_scale;
 } actmi_gemm_desc;
 
 /* Multi-head attention descriptor: softmax(scale * q k^T [+ key padding mask]) v per (batch, head).
@@ -181,8 +183,10 @@ int actmi_ensemble_step(float* ring, int32_t* tcount, const float* chunk, double
 
 /* ---- kernel-level entry points (unit tests, external callers) --------------------------------------- */
 int actmi_op_gemm(const actmi_gemm_desc* d, void* stream);
-/* weight preparation for actmi_gemm_desc.b_split: dst = fp16-split image of src (device pointers, may not alias) */
-int actmi_op_split16(const float* src, float* dst, int64_t nfloats, void* stream);
+/* weight preparation for actmi_gemm_desc.b_split: dst = fp16-split image of src * scale (device pointers, may not
+ * alias).  scale must be a power of two with |src| * scale < 65504; 256 suits network weights: pieces of values
+ * around 1e-2 then stay normal fp16 numbers (full 22-bit split) instead of subnormals. */
+int actmi_op_split16(const float* src, float* dst, int64_t nfloats, float scale, void* stream);
 int actmi_op_attention(const actmi_attn_desc* d, void* stream);
 int actmi_op_layernorm(const float* x, const float* res, int res_mod, const float* w, const float* b, const float* w2,
                        const float* b2, float* y, int M, int D, float eps, void* stream);
@@ -199,6 +203,9 @@ int actmi_debug_tensor(actmi_handle h, const char* name, const float** dev_ptr, 
 /* debug: make the next forwards return right after the named stage ("" = run everything); the maps of the
  * trunk live in rotating buffers, so a stage is only readable when the forward stopped there. */
 int actmi_debug_stop_after(actmi_handle h, const char* stage);
+/* precision of the handle's forward GEMMs / convolutions: ACTMI_PREC_F32 or ACTMI_PREC_F16X3 (the default, unless the
+ * environment says ACTMI_GEMM_PREC=f32).  Call before actmi_finalize (the split weight image is built there). */
+int actmi_set_gemm_prec(actmi_handle h, int prec);
 
 /* ---- per-launch HIP-event profiler (bench.py roofline leg) --------------------------------------- */
 /* When enabled, every kernel launch of the library is bracketed by two events on its stream.  The report is a

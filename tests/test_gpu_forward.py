@@ -14,8 +14,8 @@ from actmi.engine import ACTEngine  # noqa: E402
 ATOL = 1e-4
 
 
-def _engine(cfg, sd_np, max_batch):
-    eng = ACTEngine(cfg, max_batch=max_batch)
+def _engine(cfg, sd_np, max_batch, prec=None):
+    eng = ACTEngine(cfg, max_batch=max_batch, gemm_prec=prec)
     eng.load_state_dict(sd_np)
     eng.finalize()
     return eng
@@ -26,18 +26,19 @@ def _to_nchw(t, G, B):
     return t
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
 @pytest.mark.parametrize("name", ["tiny", "tiny_c3", "full3", "full4"])
-def test_forward_matches_reference_golden(name):
+def test_forward_matches_reference_golden(name, prec):
     z, cfg = load_fixture(name)
     sd_np, inp = regenerate(z, cfg, with_actions=True)
     B = int(z["batch"])
-    eng = _engine(cfg, sd_np, B)
+    eng = _engine(cfg, sd_np, B, prec)
     d = eng.device
     qpos = torch.from_numpy(inp["qpos"]).to(d)
     img_u8 = torch.from_numpy(inp["image_u8"]).to(d)
     a = eng.forward_infer(qpos, img_u8).cpu().numpy()
     err = np.abs(a - z["infer.a_hat"]).max()
-    print(f"{name}: max|a_hat - ref| = {err:.3e}")
+    print(f"{name} [{prec}]: max|a_hat - ref| = {err:.3e}")
     assert err <= ATOL
     # the reference's own input contract (f32 NCHW in [0,1]) gives the same result
     img_f32 = torch.from_numpy(W.u8_nhwc_to_f32_nchw(inp["image_u8"])).to(d)

@@ -1,6 +1,8 @@
 """Kernel-level parity of the HIP path (through the C ABI) against plain torch fp32 CPU references.
 Tolerances: fp32 MFMA is an exact fp32 fma chain, so differences are summation-order only; bounds below are
-relative to the result scale and an order of magnitude above what fp32 reassociation produces at these K."""
+relative to the result scale and an order of magnitude above what fp32 reassociation produces at these K.
+The GEMM / implicit-conv tests run in both precisions: "f32" (native fp32 MFMA) and "f16x3" (operands split exactly
+into two fp16 pieces, three fp16 MFMA products, fp32 accumulation: per-product error 2^-22, same bounds)."""
 import numpy as np
 import pytest
 import torch
@@ -20,20 +22,73 @@ def rel_err(got, exp):
     return float((got - exp).abs().max() / (exp.abs().max() + 1e-30))
 
 
+PRECS = ["f32", "f16x3"]
+
+
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("M,N,K", [(1, 512, 512), (37, 16, 64), (300, 512, 4608), (1202, 1536, 512), (129, 65, 36),
                                    (800, 3200, 512), (2404, 512, 3200), (64, 64, 4)])
-def test_gemm_shapes(M, N, K):
+def test_gemm_shapes(M, N, K, prec):
     g = torch.Generator().manual_seed(M * 7 + N)
     A = torch.randn(M, K, generator=g)
     W = torch.randn(N, K, generator=g)
     b = torch.randn(N, generator=g)
     exp = F.linear(A.double(), W.double(), b.double())
-    got = ops.gemm(A.to(dev()), W.to(dev()), bias=b.to(dev()))
+    got = ops.gemm(A.to(dev()), W.to(dev()), bias=b.to(dev()), prec=prec)
     # a K-long sequential fp32 fma chain: error grows ~sqrt(K) ulp of the running sum
     assert rel_err(got, exp) < 1.5e-6 * max(1.0, (K / 512) ** 0.5)
+    if prec == "f16x3" and K % 4 == 0:
+        # weights split ahead of time (what the engine does at finalize) give the same bits as splitting in the kernel
+        got2 = ops.gemm(A.to(dev()), ops.split16(W.to(dev())), bias=b.to(dev()), prec=prec, w_split=True)
+        assert torch.equal(got, got2)
 
 
-def test_gemm_epilogue_features():
+def test_split16_is_an_exact_two_piece_split():
+    """hi = rn16(x), lo = rn16(x - hi): hi + lo reproduces x to 2^-22 relative; tiny values survive as fp16
+    subnormals (absolute error floor 2^-25); the split image keeps the fp32 matrix's addressing (4 hi halfs + 4 lo halfs
+    in the 16 bytes of every aligned group of 4 floats)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1024, 64, generator=g) * torch.logspace(-6, 4, 1024).unsqueeze(1)
+    x[0, :4] = torch.tensor([0.0, -0.0, 65503.0, -1.0])
+    s = ops.split16(x.to(dev())).cpu()
+    halves = s.view(torch.float16).view(-1, 8).float().double()          # per group: hi0..3, lo0..3
+    hi, lo = halves[:, :4].reshape(x.shape), halves[:, 4:].reshape(x.shape)
+    xd = x.double()
+    assert torch.equal(hi, x.half().double())                            # round-to-nearest-even fp16
+    assert torch.equal(lo, (xd - hi).float().half().double())
+    err = (hi + lo - xd).abs()
+    # relative 2^-22, with the absolute floor of the fp16 subnormal grid (2^-24 spacing -> 2^-25 rounding error)
+    assert bool((err <= torch.maximum(xd.abs() * 2.0 ** -22, torch.tensor(2.0 ** -25, dtype=torch.float64))).all())
+
+
+@pytest.mark.parametrize("a_scale", [1e-2, 1.0, 300.0])
+def test_gemm_f16x3_magnitudes(a_scale):
+    """the engine's operating range: activations from 1e-2 to a few hundred against weights around 2e-2 whose split
+    image carries the 2^8 scale (lo pieces stay normal fp16 numbers) -> fp32-grade accuracy"""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 256, 192, 512
+    A, W = torch.randn(M, K, generator=g) * a_scale, torch.randn(N, K, generator=g) * 0.02
+    exp = F.linear(A.double(), W.double())
+    got = ops.gemm(A.to(dev()), ops.split16(W.to(dev()), 256.0), prec="f16x3", w_split=256.0)
+    assert rel_err(got, exp) < 2e-6
+
+
+def test_gemm_f16x3_tiny_operands_degrade_to_an_absolute_floor():
+    """both operands around 1e-4 (below the fp16 normal range, unscaled): each piece sits on the 2^-24 subnormal grid,
+    so the element error is absolute (2^-25), i.e. ~2^-12 relative at this magnitude -- documented limit of the mode;
+    callers with such operands pre-scale by a power of two (as the engine does for weights) or use prec="f32"."""
+    g = torch.Generator().manual_seed(12)
+    M, N, K = 128, 128, 512
+    A, W = torch.randn(M, K, generator=g) * 1e-4, torch.randn(N, K, generator=g) * 1e-4
+    exp = F.linear(A.double(), W.double())
+    got = ops.gemm(A.to(dev()), W.to(dev()), prec="f16x3")
+    assert rel_err(got, exp) < 2e-3
+    got32 = ops.gemm(A.to(dev()), W.to(dev()), prec="f32")
+    assert rel_err(got32, exp) < 2e-6
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_gemm_epilogue_features(prec):
     g = torch.Generator().manual_seed(3)
     M, N, K, mod = 250, 200, 128, 50
     A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
@@ -53,14 +108,15 @@ def test_gemm_epilogue_features():
     exp[rowmap.long()] = full
     d = dev()
     got = ops.gemm(A.to(d), W.to(d), bias=bias.to(d), scale=scale.to(d), res=res.to(d), res_mod=7, relu=True,
-                   a_add=add.to(d), add_mod=mod, add_ncols=ncols, rowmap=rowmap.to(d), out_rows=M + 11)
+                   a_add=add.to(d), add_mod=mod, add_ncols=ncols, rowmap=rowmap.to(d), out_rows=M + 11, prec=prec)
     assert rel_err(got, exp) < 2e-6
 
 
 @pytest.mark.parametrize("G,B,H,W,Cin,Cout,k,stride,pad", [
     (2, 2, 12, 16, 8, 8, 3, 1, 1), (3, 1, 15, 20, 64, 128, 3, 2, 1), (2, 2, 16, 24, 16, 32, 1, 2, 0),
     (1, 2, 30, 40, 256, 256, 3, 1, 1), (4, 1, 15, 20, 512, 512, 3, 1, 1)])
-def test_conv_implicit_gemm(G, B, H, W, Cin, Cout, k, stride, pad):
+@pytest.mark.parametrize("prec", PRECS)
+def test_conv_implicit_gemm(G, B, H, W, Cin, Cout, k, stride, pad, prec):
     g = torch.Generator().manual_seed(G * 100 + Cin)
     x = torch.randn(G, B, Cin, H, W, generator=g)
     w = torch.randn(G, Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
@@ -73,7 +129,7 @@ def test_conv_implicit_gemm(G, B, H, W, Cin, Cout, k, stride, pad):
     d = dev()
     got = ops.conv2d_nhwc(x.permute(0, 1, 3, 4, 2).contiguous().to(d), w.permute(0, 1, 3, 4, 2).contiguous().to(d),
                           scale.to(d), bias.to(d), res.permute(0, 1, 3, 4, 2).contiguous().to(d), relu=True,
-                          stride=stride, pad=pad)
+                          stride=stride, pad=pad, prec=prec)
     assert rel_err(got.permute(0, 1, 4, 2, 3), exp) < 2e-6 * max(1.0, (Cin * k * k / 512) ** 0.5)
 
 
