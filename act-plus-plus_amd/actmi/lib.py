@@ -55,7 +55,7 @@ class AttnDesc(C.Structure):
         ("kpm", C.c_void_p), ("kpm_bs", C.c_int64), ("lse", C.c_void_p),
         ("B", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("HD", C.c_int32),
         ("scale", C.c_float), ("ws", C.c_void_p), ("ws_floats", C.c_int64),
-        ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
+        ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("prec", C.c_int32),
     ]
 
 

@@ -76,7 +76,7 @@ def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1
     return out
 
 
-def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False, split=True, drop_p=0.0, drop_seed=0):
+def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False, split=True, drop_p=0.0, drop_seed=0, prec=None):
     """q [B,Nq,D] (or [Nq,D] when q_shared), k/v [B,Nk,D] (views with row stride allowed); returns [B,Nq,D]."""
     lib = L.load()
     B, Nk, D = k.shape
@@ -98,6 +98,7 @@ def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False, split=T
     d.B, d.H, d.Nq, d.Nk, d.HD = B, nheads, Nq, Nk, hd
     d.scale = 1.0 / (hd ** 0.5)
     d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)
+    d.prec = PREC[prec]
     L.check(lib.actmi_op_attention(C.byref(d), L.current_stream_ptr()), None, "op_attention")
     return (out, lse) if want_lse else out
 

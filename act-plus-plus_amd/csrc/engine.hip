@@ -527,6 +527,7 @@ int engine_encoder_layer(actmi_ctx* ctx, const EncW& w, float* x, const float* p
     at.kpm = kpm; at.kpm_bs = n;
     at.B = B; at.H = g.nheads; at.Nq = n; at.Nk = n; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
     at.ws = ctx->attn_ws; at.ws_floats = ctx->attn_ws_floats;
+    at.prec = ctx->gemm_prec;
     CHK(launch_attention(at, st, &ctx->err));
     GemmArgs op = linear_args(ctx->ATT, D, M, D, w.attn.out_w, D, w.attn.out_b, ctx->Y, D);
     op.res = x; op.ldres = D;
@@ -559,6 +560,7 @@ int engine_decoder_infer(actmi_ctx* ctx, int B, float* a_hat, hipStream_t st) {
     at.O = ctx->dO; at.o_bs = (int64_t)Q * D; at.o_rs = D;
     at.B = B; at.H = g.nheads; at.Nq = Q; at.Nk = N; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
     at.ws = ctx->attn_ws; at.ws_floats = ctx->attn_ws_floats;
+    at.prec = ctx->gemm_prec;
     CHK(launch_attention(at, st, &ctx->err));
     const int M = B * Q;
     GemmArgs op = linear_args(ctx->dO, D, M, D, d.cross.out_w, D, d.cross.out_b, ctx->dY, D);

@@ -136,6 +136,8 @@ typedef struct actmi_attn_desc {
     /* dropout on the attention weights (nn.MultiheadAttention dropout): mask = f(drop_seed, ((b*H+h)*Nq+q)*Nk+key) */
     float drop_p;
     uint64_t drop_seed;
+    /* product precision, as in actmi_gemm_desc.prec (0 = ACTMI_GEMM_PREC from the environment, else native fp32) */
+    int32_t prec;
 } actmi_attn_desc;
 
 int actmi_version(void);

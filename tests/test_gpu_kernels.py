@@ -136,7 +136,8 @@ def test_conv_implicit_gemm(G, B, H, W, Cin, Cout, k, stride, pad, prec):
 @pytest.mark.parametrize("B,H,Nq,Nk,hd,masked,shared", [(2, 8, 1202, 1202, 64, False, False), (3, 8, 100, 1202, 64, False, True),
                                                        (4, 8, 102, 102, 64, True, False), (2, 4, 14, 14, 16, False, False),
                                                        (2, 4, 10, 12, 16, True, False), (1, 2, 33, 65, 32, True, False)])
-def test_attention(B, H, Nq, Nk, hd, masked, shared):
+@pytest.mark.parametrize("prec", PRECS)
+def test_attention(B, H, Nq, Nk, hd, masked, shared, prec):
     g = torch.Generator().manual_seed(Nq + Nk)
     D = H * hd
     q = torch.randn((Nq, D) if shared else (B, Nq, D), generator=g)
@@ -157,12 +158,13 @@ def test_attention(B, H, Nq, Nk, hd, masked, shared):
     d = dev()
     kvd = kv.to(d)
     got, lse = ops.attention(q.to(d), kvd[..., :D], kvd[..., D:], H, kpm=kpm.to(torch.uint8).to(d) if masked else None,
-                             q_shared=shared, want_lse=True)
+                             q_shared=shared, want_lse=True, prec=prec)
     assert rel_err(got, exp) < 3e-6
     assert rel_err(lse, torch.logsumexp(s, -1)) < 3e-6
 
 
-def test_attention_online_softmax_rescale_branch():
+@pytest.mark.parametrize("prec", PRECS)
+def test_attention_online_softmax_rescale_branch(prec):
     """Force the running max to jump late: one key dominates in the LAST tile (rule: a rare branch needs its own test)."""
     B, H, Nq, Nk, hd = 1, 1, 40, 200, 64
     g = torch.Generator().manual_seed(0)
@@ -173,7 +175,7 @@ def test_attention_online_softmax_rescale_branch():
     s = (q.double() @ k.double().transpose(-1, -2)) / 8.0
     exp = torch.softmax(s, -1) @ v.double()
     d = dev()
-    got = ops.attention(q.to(d), k.to(d), v.to(d), 1)
+    got = ops.attention(q.to(d), k.to(d), v.to(d), 1, prec=prec)
     assert rel_err(got, exp) < 3e-6
 
 
