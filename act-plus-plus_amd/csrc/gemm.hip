@@ -129,6 +129,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     const float* add_ptr[NLA];
     int a_hi0[NLA], a_wi0[NLA];
     bool a_ok[NLA];
+    // A_CONV fast path (block-uniform): when Cin is a multiple of the K tile, a K tile lies inside ONE filter tap, so the
+    // tap (r,s) and its channel base are scalars per tile and the per-row work shrinks to a mask-bit test and one add
+    // (the general path decomposes k per thread with two integer divisions per K tile).
+    const bool conv_fast = AMODE == A_CONV && (p.Cin % BK) == 0 && p.KH * p.KW <= 32 &&
+                           (int64_t)p.H * p.W * p.Cin < ((int64_t)1 << 30);
+    unsigned a_tapmask[AMODE == A_CONV ? NLA : 1];
+    int a_off0[AMODE == A_CONV ? NLA : 1];
+    const float conv_inv_tpr = (AMODE == A_CONV && conv_fast) ? 1.0f / (float)(p.Cin / BK) : 0.f;
+    const float conv_inv_kw = (AMODE == A_CONV) ? 1.0f / (float)p.KW : 0.f;
     const bool use_add = (AMODE == A_NADD) && n0 < p.add_ncols;       // block-uniform
     // T-form micro tile of A: out group og (4 consecutive m), k group kg (4 consecutive k)
     const int a_og = t % (BM / 4), a_kg = t / (BM / 4);
@@ -153,6 +162,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
                 a_ptr[i] = A + (int64_t)b * p.img_stride;
                 a_hi0[i] = ho * p.stride - p.pad;
                 a_wi0[i] = wo * p.stride - p.pad;
+                if (conv_fast) {
+                    // bit (r*KW+s): filter tap (r,s) of this output pixel lies inside the image
+                    unsigned mk = 0;
+                    for (int r = 0; r < p.KH; ++r)
+                        for (int q = 0; q < p.KW; ++q)
+                            if (a_ok[i] && (unsigned)(a_hi0[i] + r) < (unsigned)p.H && (unsigned)(a_wi0[i] + q) < (unsigned)p.W)
+                                mk |= 1u << (r * p.KW + q);
+                    a_tapmask[i] = mk;
+                    a_off0[i] = (a_hi0[i] * p.W + a_wi0[i]) * p.Cin + cidx * 4;
+                }
             } else {   // A_DGRAD: rows are input pixels (b, hi, wi)
                 const int hw = p.H * p.W;
                 const int b = mm / hw, rem = mm - b * hw;
@@ -223,6 +242,21 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
                     R.ra[i] = ld4(a_ptr[i] + kc);
                     if (AMODE == A_NADD) R.rx[i] = ld4(add_ptr[i] + kc);
                     R.ra_ok[i] = a_ok[i] && kok;
+                }
+            } else if (AMODE == A_CONV && conv_fast) {
+                // uniform tap of this K tile (small exact integer divisions via reciprocal multiply: kt < 2^20)
+                const int tpr = p.Cin / BK;
+                const int rs = (int)(((float)kt + 0.5f) * conv_inv_tpr);
+                const int cb = (kt - rs * tpr) * BK;
+                const int r = (int)(((float)rs + 0.5f) * conv_inv_kw);
+                const int q = rs - r * p.KW;
+                const int delta = (r * p.W + q) * p.Cin + cb;
+#pragma unroll
+                for (int i = 0; i < NLA; ++i) {
+                    const bool inb = (a_tapmask[i] >> rs) & 1u;
+                    const int off = inb ? a_off0[i] + delta : 0;
+                    R.ra[i] = ld4(a_ptr[i] + off);
+                    R.ra_ok[i] = inb;
                 }
             } else if (AMODE == A_CONV) {
                 const int rs = k / p.Cin;

@@ -34,8 +34,8 @@ PEAK_FP16_MATRIX_TFLOPS = 16 * 157.3     # dense F16/BF16 MFMA = 16x the f32 MFM
 
 ARITH = {
     "f16x3": "fp32 in / fp32 out / fp32 accumulate; GEMM and conv products on the fp16 matrix pipe with both operands "
-             "split exactly into two fp16 pieces (3 MFMA products per fp32 product, fp32-grade parity); attention, "
-             "conv1, LayerNorm in native fp32",
+             "split exactly into two fp16 pieces (3 MFMA products per fp32 product, fp32-grade parity: GEMMs, 3x3/1x1 "
+             "convolutions, attention); conv1 stem on the native fp32 MFMA; LayerNorm / softmax / pooling fp32 VALU",
     "f32": "fp32 everywhere, native fp32 MFMA (v_mfma_f32_32x32x2_f32)",
 }
 
@@ -63,9 +63,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (metric is quoted at 8)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = headline policy-query metric; train = ACT training step (forward+backward+AdamW), fp32")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step as ONE captured hipGraph (per-kernel events then come from extra eager steps "
-                         "after the timed region, since events cannot bracket kernels inside a graph)")
+    ap.add_argument("--graph", action="store_true", default=True,
+                    help="(default) replay the step as ONE captured hipGraph; per-kernel events then come from extra eager "
+                         "steps after the timed region, since events cannot bracket kernels inside a graph")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch the step's kernels eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     args = ap.parse_args()
