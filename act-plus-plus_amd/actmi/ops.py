@@ -122,7 +122,7 @@ def maxpool3x3s2(x):
     return y
 
 
-def conv1(image, w_oihw, scale, bias):
+def conv1(image, w_oihw, scale, bias, prec=None):
     """image u8 [B,C,H,W,3] or f32 [B,C,3,H,W]; w [C,Cout,3,7,7]; scale/bias [C,Cout] -> [C,B,Ho,Wo,Cout]."""
     lib = L.load()
     image = image.contiguous()
@@ -137,7 +137,7 @@ def conv1(image, w_oihw, scale, bias):
     out = torch.zeros((Cn, B, Ho, Wo, Cout), dtype=torch.float32, device=image.device)
     ws = torch.empty(Cn * Cout * 148 + 768, dtype=torch.float32, device=image.device)
     L.check(lib.actmi_op_conv1(_p(image), fmt, _p(w_oihw), _p(scale), _p(bias), _p(out), _p(ws), B, Cn, H, W, Cout,
-                               L.current_stream_ptr()), None, "op_conv1")
+                               PREC[prec], L.current_stream_ptr()), None, "op_conv1")
     return out
 
 

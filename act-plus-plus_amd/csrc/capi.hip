@@ -143,7 +143,7 @@ int actmi_op_maxpool3x3s2(const float* in, float* out, int nimg, int H, int W, i
 }
 
 int actmi_op_conv1(const void* image, int image_fmt, const float* w_oihw, const float* scale, const float* bias,
-                   float* out, float* workspace, int B, int C, int H, int W, int Cout, void* stream) {
+                   float* out, float* workspace, int B, int C, int H, int W, int Cout, int prec, void* stream) {
     g_op_error.clear();
     float* wp = workspace;
     float* lut = workspace + (int64_t)C * Cout * 148;
@@ -158,6 +158,7 @@ int actmi_op_conv1(const void* image, int image_fmt, const float* w_oihw, const 
     Conv1Args a;
     a.image = image; a.fmt = image_fmt; a.lut = lut; a.w = wp; a.scale = scale; a.bias = bias; a.out = out;
     a.B = B; a.C = C; a.H = H; a.W = W; a.Ho = (H + 6 - 7) / 2 + 1; a.Wo = (W + 6 - 7) / 2 + 1; a.Cout = Cout;
+    a.prec = prec;
     return launch_conv1(a, S(stream), &g_op_error);
 }
 

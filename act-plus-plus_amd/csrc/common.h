@@ -31,6 +31,7 @@ struct Conv1Args {
     const float* bias;    // [C][Cout]
     float* out;           // camera-major NHWC [C][B][Ho][Wo][Cout]
     int B, C, H, W, Ho, Wo, Cout;
+    int prec = 0;         // ACTMI_PREC_* (0 = environment / native fp32)
 };
 int launch_conv1(const Conv1Args& a, hipStream_t st, std::string* err);
 

@@ -12,10 +12,12 @@
 // camera's weights (row stride 149 floats: conflict-free).  Blocks are persistent over tiles so the 37 KB
 // weight image is staged once per block.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int KREAL = 147, KPAD = 148, WSTRIDE = 149;
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 constexpr int TILE_P = 64;                 // output pixels per tile
 constexpr int PCOLS = 2 * TILE_P + 5;      // 133 input columns
 constexpr int PSTRIDE = 400;               // floats per patch row (133*3 = 399, padded)
@@ -199,11 +201,272 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args p, int tiles_per_r
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp16-split stem (PREC f16x3, see gemm.hip): same contract and outputs, products on v_mfma_f32_32x32x16_f16 with both
+// operands split exactly into (hi, lo) fp16 pieces.
+//   tile  = 2 output rows x 64 output pixels x all Cout channels; wave w owns row (w>>1), pixels 32*(w&1).., and BOTH
+//           32-channel MFMA tiles, so one A fragment feeds 6 MFMAs.
+//   patch = 9 input rows x 399 values staged as halfs, hi row | lo row (816 B each); the u8 path needs no conversion at
+//           all: the lookup table holds the split of every normalised byte value ((hi | lo << 16) per entry).
+//   K     = 7 filter rows x 24 (21 real taps x channels + 3 zero-weight pad) = 21 groups of 8, two groups per MFMA step
+//           (one per lane half), 11 steps; the A group of pixel p, filter row r, group g is the 16 bytes at
+//           patch[2*row + r][6p + 8g]: 4-byte aligned only, hence 4 ds_read_b32.
+//   B     = this camera's weights x 2^8 (keeps the lo pieces normal fp16 numbers; undone in the epilogue scale) as
+//           [n][22 groups][8 halfs] hi | lo, row stride 368 B (conflict-free ds_read_b128).
+// 66 MFMAs of 32 cycles per wave and 128 output pixels, against 74 of 64 cycles per 64 pixels for the fp32 kernel.
+constexpr int F_TP = 64, F_ROWS = 2, F_PROWS = 2 * F_ROWS + 5;      // 9 input rows
+constexpr int F_RB = 816;                                          // bytes per half-row (408 halfs)
+constexpr int F_PATCH = F_PROWS * 2 * F_RB;                        // bytes per patch buffer
+constexpr int F_NG = 22;                                           // contraction groups incl. the zero one
+constexpr int F_WROW = 368;                                        // bytes per channel row of one weight piece
+constexpr int F_WBYTES = 64 * F_WROW;
+constexpr int F_SMEM = 2 * F_WBYTES + 2 * F_PATCH + 3 * 256 * 4;
+constexpr float F_WSCALE = 256.f;
+
+__device__ __forceinline__ uint32_t split1(float v) {              // (hi | lo << 16) of one value
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    return (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256) void conv1_f16x3_kernel(Conv1Args p, int tiles_per_row, int tiles_per_cam) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned char* s_wh = reinterpret_cast<unsigned char*>(smem_raw);
+    unsigned char* s_wl = s_wh + F_WBYTES;
+    unsigned char* s_patch = s_wl + F_WBYTES;                      // two buffers of F_PATCH bytes
+    uint32_t* s_lut = reinterpret_cast<uint32_t*>(s_patch + 2 * F_PATCH);
+    const int cam = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int prow = wave >> 1, phalf = wave & 1;
+
+    // weights: [Cout][148] (k = r*21 + x) -> [n][group r*3+g][8], split, scaled; everything else zero
+    const float* wg = p.w + (int64_t)cam * p.Cout * KPAD;
+    for (int e = t; e < 64 * F_NG * 8; e += 256) {
+        const int n = e / (F_NG * 8), rem = e - n * (F_NG * 8);
+        const int gi = rem >> 3, j = rem & 7;
+        const int r = gi / 3, g = gi - r * 3, x = 8 * g + j;
+        float v = 0.f;
+        if (n < p.Cout && gi < 21 && x < 21) v = wg[n * KPAD + r * 21 + x] * F_WSCALE;
+        const uint32_t hl = split1(v);
+        *reinterpret_cast<uint16_t*>(s_wh + n * F_WROW + gi * 16 + j * 2) = (uint16_t)(hl & 0xffffu);
+        *reinterpret_cast<uint16_t*>(s_wl + n * F_WROW + gi * 16 + j * 2) = (uint16_t)(hl >> 16);
+    }
+    for (int e = t; e < 3 * 256; e += 256) s_lut[e] = (FMT == 0) ? split1(p.lut[e]) : 0u;
+    for (int e = t; e < 2 * F_PATCH / 4; e += 256) reinterpret_cast<uint32_t*>(s_patch)[e] = 0u;
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+    __syncthreads();
+
+    float sc[2], bi[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = nt * 32 + li;
+        sc[nt] = (n < p.Cout) ? p.scale[cam * p.Cout + n] * (1.f / F_WSCALE) : 0.f;
+        bi[nt] = (n < p.Cout) ? p.bias[cam * p.Cout + n] : 0.f;
+    }
+
+    constexpr int NS = (FMT == 0) ? (F_PROWS * 101 + 255) / 256 : (F_PROWS * 3 * PCOLS + 255) / 256;
+    uint32_t sreg[NS];
+    const int hpairs = (p.Ho + F_ROWS - 1) / F_ROWS;
+    auto tile_coords = [&](int tile, int& b, int& ho0, int& wo0) {
+        b = tile / (hpairs * tiles_per_row);
+        const int rem = tile - b * (hpairs * tiles_per_row);
+        const int hp = rem / tiles_per_row;
+        ho0 = hp * F_ROWS;
+        wo0 = (rem - hp * tiles_per_row) * F_TP;
+    };
+    auto fetch = [&](int tile) {
+        int b, ho0, wo0;
+        tile_coords(tile, b, ho0, wo0);
+        const int64_t img = (int64_t)b * p.C + cam;
+        const int hi0 = 2 * ho0 - 3, wi0 = 2 * wo0 - 3;
+        if (FMT == 0) {
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(p.image) + img * (int64_t)p.H * p.W * 3;
+            const int64_t img_bytes = (int64_t)p.H * p.W * 3;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int e = t + 256 * i;
+                const int r = e / 101, j = e - r * 101;
+                const int hi = hi0 + r;
+                uint32_t v = 0;
+                if (r < F_PROWS && (unsigned)hi < (unsigned)p.H) {
+                    const int64_t a0 = ((int64_t)hi * p.W + wi0) * 3;
+                    int64_t wa = ((a0 >> 2) + j) << 2;
+                    if (wa < 0) wa = 0;
+                    if (wa > img_bytes - 4) wa = (img_bytes - 4) & ~int64_t(3);
+                    v = *reinterpret_cast<const uint32_t*>(src + wa);
+                }
+                sreg[i] = v;
+            }
+        } else {
+            const float* src = reinterpret_cast<const float*>(p.image) + img * 3 * (int64_t)p.H * p.W;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int e = t + 256 * i;
+                const int rc = e / PCOLS, pc = e - rc * PCOLS;
+                const int r = rc / 3, c = rc - r * 3;
+                const int hi = hi0 + r, wi = wi0 + pc;
+                float v = 0.f;
+                if (e < F_PROWS * 3 * PCOLS && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                    v = src[((int64_t)c * p.H + hi) * p.W + wi];
+                sreg[i] = __float_as_uint(v);
+            }
+        }
+    };
+    auto put = [&](unsigned char* patch, int r, int x, uint32_t hl) {
+        *reinterpret_cast<uint16_t*>(patch + r * 2 * F_RB + x * 2) = (uint16_t)(hl & 0xffffu);
+        *reinterpret_cast<uint16_t*>(patch + r * 2 * F_RB + F_RB + x * 2) = (uint16_t)(hl >> 16);
+    };
+    auto commit = [&](int tile, unsigned char* patch) {
+        int b, ho0, wo0;
+        tile_coords(tile, b, ho0, wo0);
+        const int hi0 = 2 * ho0 - 3, wi0 = 2 * wo0 - 3;
+        if (FMT == 0) {
+            const int64_t img_bytes = (int64_t)p.H * p.W * 3;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int e = t + 256 * i;
+                const int r = e / 101, j = e - r * 101;
+                const int hi = hi0 + r;
+                if (r >= F_PROWS) continue;
+                const bool row_ok = (unsigned)hi < (unsigned)p.H;
+                const int64_t a0 = ((int64_t)hi * p.W + wi0) * 3;
+                int64_t wa = ((a0 >> 2) + j) << 2;
+                const int64_t wa_req = wa;
+                if (wa < 0) wa = 0;
+                if (wa > img_bytes - 4) wa = (img_bytes - 4) & ~int64_t(3);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t ba = wa_req + k;
+                    const int x = (int)(ba - a0);
+                    if (x < 0 || x >= PCOLS * 3) continue;
+                    const int pc = x / 3, c = x - pc * 3;
+                    const int wi = wi0 + pc;
+                    uint32_t hl = 0u;
+                    if (row_ok && (unsigned)wi < (unsigned)p.W) {
+                        const int64_t sh = ba - wa;            // the (possibly clamped) word holds this byte if 0 <= sh < 4
+                        if (sh >= 0 && sh < 4) hl = s_lut[c * 256 + ((sreg[i] >> (8 * sh)) & 0xFF)];
+                    }
+                    put(patch, r, x, hl);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int e = t + 256 * i;
+                if (e >= F_PROWS * 3 * PCOLS) continue;
+                const int rc = e / PCOLS, pc = e - rc * PCOLS;
+                const int r = rc / 3, c = rc - r * 3;
+                const int hi = hi0 + r, wi = wi0 + pc;
+                float v = 0.f;
+                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                    v = (__uint_as_float(sreg[i]) - mean[c]) / stdv[c];
+                put(patch, r, pc * 3 + c, split1(v));
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < tiles_per_cam) {
+        fetch(tile);
+        commit(tile, s_patch);
+    }
+    __syncthreads();
+    int cur = 0;
+    const unsigned char* bbase = s_wh + li * F_WROW + lh * 16;
+    for (; tile < tiles_per_cam; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        const bool has_next = next < tiles_per_cam;
+        if (has_next) fetch(next);
+        int b, ho0, wo0;
+        tile_coords(tile, b, ho0, wo0);
+        const int64_t oimg = (int64_t)cam * p.B + b;
+        {
+            const unsigned char* abase = s_patch + cur * F_PATCH + (2 * prow) * 2 * F_RB + 12 * (phalf * 32 + li);
+            f32x16 acc[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 11; ++s) {
+                // this lane half's contraction group 2s+lh -> (filter row, 8-wide window); the 22nd group has zero weights
+                constexpr int NOFF = 0;
+                const int g0 = 2 * s, g1 = (2 * s + 1 < 21) ? 2 * s + 1 : 20;
+                const int off0 = (g0 / 3) * 2 * F_RB + (g0 % 3) * 16, off1 = (g1 / 3) * 2 * F_RB + (g1 % 3) * 16;
+                const unsigned char* ap = abase + (lh ? off1 : off0) + NOFF;
+                uint4 ah, al;
+                ah.x = *reinterpret_cast<const uint32_t*>(ap + 0);  ah.y = *reinterpret_cast<const uint32_t*>(ap + 4);
+                ah.z = *reinterpret_cast<const uint32_t*>(ap + 8);  ah.w = *reinterpret_cast<const uint32_t*>(ap + 12);
+                al.x = *reinterpret_cast<const uint32_t*>(ap + F_RB + 0);  al.y = *reinterpret_cast<const uint32_t*>(ap + F_RB + 4);
+                al.z = *reinterpret_cast<const uint32_t*>(ap + F_RB + 8);  al.w = *reinterpret_cast<const uint32_t*>(ap + F_RB + 12);
+                const h16x8 xh = __builtin_bit_cast(h16x8, ah), xl = __builtin_bit_cast(h16x8, al);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const h16x8 yh = __builtin_bit_cast(h16x8, *reinterpret_cast<const uint4*>(bbase + nt * 32 * F_WROW + s * 32));
+                    const h16x8 yl = __builtin_bit_cast(h16x8, *reinterpret_cast<const uint4*>(bbase + F_WBYTES + nt * 32 * F_WROW + s * 32));
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yh, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yl, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, acc[nt], 0, 0, 0);
+                }
+            }
+            const int ho = ho0 + prow;
+            if (ho < p.Ho) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int n = nt * 32 + li;
+                    if (n < p.Cout) {
+                        float* orow = p.out + ((oimg * p.Ho + ho) * (int64_t)p.Wo) * p.Cout + n;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int wo = wo0 + phalf * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                            if (wo < p.Wo) orow[(int64_t)wo * p.Cout] = fmaxf(acc[nt][e] * sc[nt] + bi[nt], 0.f);
+                        }
+                    }
+                }
+            }
+        }
+        if (has_next) commit(next, s_patch + (cur ^ 1) * F_PATCH);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 }  // namespace
 
 int launch_conv1(const Conv1Args& a, hipStream_t st, std::string* err) {
     if (a.Cout > 64 || a.Cout < 1) { if (err) *err = "conv1: Cout must be in 1..64"; return -2; }
     if (a.Ho != (a.H + 6 - 7) / 2 + 1 || a.Wo != (a.W + 6 - 7) / 2 + 1) { if (err) *err = "conv1: bad output size"; return -2; }
+    static const int env_prec = [] {
+        const char* e = getenv("ACTMI_GEMM_PREC");
+        if (!e) return ACTMI_PREC_F32;
+        return (e[0] == 'f' && e[1] == '3') ? ACTMI_PREC_F32 : ACTMI_PREC_F16X3;
+    }();
+    const int prec = a.prec ? a.prec : env_prec;
+    if (prec == ACTMI_PREC_F16X3) {
+        const int tiles_per_row = (a.Wo + F_TP - 1) / F_TP;
+        const int tiles_per_cam = a.B * ((a.Ho + F_ROWS - 1) / F_ROWS) * tiles_per_row;
+        int gx = tiles_per_cam < 512 ? tiles_per_cam : 512;
+        const int per = (tiles_per_cam + gx - 1) / gx;
+        gx = (tiles_per_cam + per - 1) / per;
+        dim3 grid(gx, a.C);
+        prof_begin(a.fmt == 0 ? "conv1_f16x3_kernel<0>" : "conv1_f16x3_kernel<1>", 2.0 * a.B * a.C * a.Ho * a.Wo * a.Cout * 147.0,
+                   (double)a.B * a.C * ((double)a.H * a.W * 3 * (a.fmt == 0 ? 1 : 4) + 4.0 * a.Ho * a.Wo * a.Cout), st);
+        static bool attr16 = false;
+        if (!attr16) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM) != hipSuccess) {
+                if (err) *err = "conv1: cannot raise the dynamic LDS limit";
+                return -3;
+            }
+            attr16 = true;
+        }
+        if (a.fmt == 0) hipLaunchKernelGGL(conv1_f16x3_kernel<0>, grid, dim3(256), F_SMEM, st, a, tiles_per_row, tiles_per_cam);
+        else hipLaunchKernelGGL(conv1_f16x3_kernel<1>, grid, dim3(256), F_SMEM, st, a, tiles_per_row, tiles_per_cam);
+    } else {
     const int tiles_per_row = (a.Wo + TILE_P - 1) / TILE_P;
     const int tiles_per_cam = a.B * a.Ho * tiles_per_row;
     int gx = tiles_per_cam < 512 ? tiles_per_cam : 512;
@@ -225,6 +488,7 @@ int launch_conv1(const Conv1Args& a, hipStream_t st, std::string* err) {
     }
     if (a.fmt == 0) hipLaunchKernelGGL(conv1_kernel<0>, grid, dim3(256), smem, st, a, tiles_per_row, tiles_per_cam);
     else hipLaunchKernelGGL(conv1_kernel<1>, grid, dim3(256), smem, st, a, tiles_per_row, tiles_per_cam);
+    }
     prof_end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (err) *err = std::string("conv1 launch: ") + hipGetErrorString(e); return -3; }

@@ -454,6 +454,7 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
     c1.image = image; c1.fmt = fmt; c1.lut = ctx->lut; c1.w = ctx->conv1_w; c1.scale = ctx->conv1_scale;
     c1.bias = ctx->conv1_bias; c1.out = ctx->act1; c1.B = B; c1.C = C; c1.H = g.image_h; c1.W = g.image_w;
     c1.Ho = ctx->H1; c1.Wo = ctx->W1; c1.Cout = w0;
+    c1.prec = ctx->gemm_prec;
     CHK(launch_conv1(c1, st, &ctx->err));
     CHK(launch_maxpool(ctx->act1, ctx->buf[0], C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
     float* cur = ctx->buf[0];

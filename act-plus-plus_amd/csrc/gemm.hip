@@ -138,6 +138,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     int a_off0[AMODE == A_CONV ? NLA : 1];
     const float conv_inv_tpr = (AMODE == A_CONV && conv_fast) ? 1.0f / (float)(p.Cin / BK) : 0.f;
     const float conv_inv_kw = (AMODE == A_CONV) ? 1.0f / (float)p.KW : 0.f;
+    unsigned conv_rep = 0;                      // bit r*KW set for every filter row: replicates a column mask over the rows
+    if (AMODE == A_CONV && conv_fast)
+        for (int r = 0; r < p.KH; ++r) conv_rep |= 1u << (r * p.KW);
     const bool use_add = (AMODE == A_NADD) && n0 < p.add_ncols;       // block-uniform
     // T-form micro tile of A: out group og (4 consecutive m), k group kg (4 consecutive k)
     const int a_og = t % (BM / 4), a_kg = t / (BM / 4);
@@ -164,12 +167,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
                 a_wi0[i] = wo * p.stride - p.pad;
                 if (conv_fast) {
                     // bit (r*KW+s): filter tap (r,s) of this output pixel lies inside the image
-                    unsigned mk = 0;
-                    for (int r = 0; r < p.KH; ++r)
-                        for (int q = 0; q < p.KW; ++q)
-                            if (a_ok[i] && (unsigned)(a_hi0[i] + r) < (unsigned)p.H && (unsigned)(a_wi0[i] + q) < (unsigned)p.W)
-                                mk |= 1u << (r * p.KW + q);
-                    a_tapmask[i] = mk;
+                    // (closed form, no loops: valid filter rows [r_lo, r_hi) x valid filter columns [q_lo, q_hi))
+                    const int r_lo = a_hi0[i] < 0 ? -a_hi0[i] : 0, q_lo = a_wi0[i] < 0 ? -a_wi0[i] : 0;
+                    int r_hi = p.H - a_hi0[i], q_hi = p.W - a_wi0[i];
+                    r_hi = r_hi < p.KH ? (r_hi > 0 ? r_hi : 0) : p.KH;
+                    q_hi = q_hi < p.KW ? (q_hi > 0 ? q_hi : 0) : p.KW;
+                    const unsigned colmask = (r_lo < r_hi && q_lo < q_hi) ? (((1u << q_hi) - 1u) & ~((1u << q_lo) - 1u)) : 0u;
+                    const unsigned rowsel = (unsigned)((((uint64_t)1 << (r_hi * p.KW)) - 1u) & ~(((uint64_t)1 << (r_lo * p.KW)) - 1u));
+                    a_tapmask[i] = a_ok[i] ? (rowsel & (colmask * conv_rep)) : 0u;
                     a_off0[i] = (a_hi0[i] * p.W + a_wi0[i]) * p.Cin + cidx * 4;
                 }
             } else {   // A_DGRAD: rows are input pixels (b, hi, wi)
@@ -794,20 +799,39 @@ int launch_cfg(const GemmArgs& a, hipStream_t st) {
     return launch_cfg_b<BM, BN, WM, WN, AMODE, BMODE, PREC, 0>(a, st);
 }
 
-double tile_eff(int M, int N, int nz, int BM, int BN, double factor) {
+// Estimated launch time of a tile shape, in units of "one 128x128 K tile at full speed".  Two workgroups share a CU:
+// 512 residency slots; a surplus round with at most one workgroup per CU costs one tile time, a fuller one up to two;
+// a launch that never pairs workgroups on a CU (<= 256 tiles) hides nothing (x1.3).  Per tile: a fixed prologue +
+// epilogue worth `fixed` K tiles plus nk K tiles at the shape's relative speed `eff` (both measured on the ACT shapes;
+// the fp16-split loop spends 5x fewer MFMA cycles per staged byte, so small tiles and the fixed part weigh more).
+double tile_cost(int M, int N, int K, int nz, int BM, int BN, double eff, double fixed) {
     const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * nz;
-    const long rounds = (tiles + 255) / 256;
-    return factor * ((double)M * N * nz) / ((double)rounds * 256 * BM * BN);
+    const long full = tiles / 512, f = tiles - full * 512;
+    double rounds = 2.0 * full + (f == 0 ? 0.0 : (f <= 256 ? 1.0 : 1.0 + (double)(f - 256) / 256.0));
+    if (tiles <= 256) rounds *= 1.3;
+    const double nk = (double)((K + BK - 1) / BK);
+    return rounds * ((double)BM * BN / (128.0 * 128.0)) * (fixed + nk / eff);
 }
 
 template <int AMODE, int BMODE, int PREC>
 int launch_modes(const GemmArgs& a, hipStream_t st) {
-    const int nz = (a.groups > 0 ? a.groups : 1) * (a.splitk > 1 ? a.splitk : 1);
-    // relative speed of the tile shapes at equal occupancy (measured on the ACT shapes): the fp16-split loop spends 5x
-    // fewer MFMA cycles per staged byte, so small tiles (more L2 traffic per FLOP) cost it more
-    const double eL = tile_eff(a.M, a.N, nz, 128, 128, 1.00);
-    const double eM = tile_eff(a.M, a.N, nz, 128, 64, PREC ? 0.80 : 0.95);
-    const double eS = tile_eff(a.M, a.N, nz, 64, 64, PREC ? 0.78 : 0.88);
+    const int nz = a.groups > 0 ? a.groups : 1;
+    const int Ks = a.splitk > 1 ? (a.K + a.splitk - 1) / a.splitk : a.K;
+    const int nzs = nz * (a.splitk > 1 ? a.splitk : 1);
+    const double fixed = PREC ? 10.0 : 2.5;
+    const double cL = tile_cost(a.M, a.N, Ks, nzs, 128, 128, 1.00, fixed);
+    const double cM = tile_cost(a.M, a.N, Ks, nzs, 128, 64, PREC ? 0.74 : 0.95, fixed);
+    const double cS = tile_cost(a.M, a.N, Ks, nzs, 64, 64, PREC ? 0.68 : 0.88, fixed);
+    double eL = -cL, eM = -cM, eS = -cS;
+    if (!PREC) {
+        // native fp32 MFMA: the K loop dominates a tile, so whole rounds of 256 tiles describe it well (measured)
+        auto eff = [&](int BM, int BN, double factor) {
+            const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * nzs;
+            const long rounds = (tiles + 255) / 256;
+            return factor * ((double)a.M * a.N * nzs) / ((double)rounds * 256 * BM * BN);
+        };
+        eL = eff(128, 128, 1.00); eM = eff(128, 64, 0.95); eS = eff(64, 64, 0.88);
+    }
     static const char* force = getenv("ACTMI_GEMM_CFG");      // tuning aid: L / M / S
     if (force && force[0] == 'L') return launch_cfg<128, 128, 64, 64, AMODE, BMODE, PREC>(a, st);
     if (force && force[0] == 'M') return launch_cfg<128, 64, 64, 32, AMODE, BMODE, PREC>(a, st);

@@ -196,7 +196,7 @@ int actmi_op_maxpool3x3s2(const float* in_nhwc, float* out_nhwc, int nimg, int H
 /* conv1: w is the torch OIHW [C][Cout][3][7][7] weight, scale/bias the folded FrozenBN; out camera-major NHWC */
 int actmi_op_conv1(const void* image, int image_fmt, const float* w_oihw, const float* scale, const float* bias,
                    float* out, float* workspace /* >= C*Cout*148 + 768 floats */, int B, int C, int H, int W, int Cout,
-                   void* stream);
+                   int prec /* ACTMI_PREC_*, 0 = environment / native fp32 */, void* stream);
 const char* actmi_op_last_error(void);
 
 /* intermediate activations of the last forward (parity tests): name in {"conv1","maxpool","layer1".."layer4",

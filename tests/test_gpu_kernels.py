@@ -202,8 +202,9 @@ def test_maxpool_bit_exact():
     assert torch.equal(got.permute(0, 3, 1, 2).cpu(), exp)      # max is order independent: bit exact
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("B,C,H,W,Cout", [(2, 2, 64, 96, 8), (1, 3, 96, 64, 8), (1, 1, 480, 640, 64), (2, 2, 70, 150, 64)])
-def test_conv1_u8_and_f32(B, C, H, W, Cout):
+def test_conv1_u8_and_f32(B, C, H, W, Cout, prec):
     g = torch.Generator().manual_seed(H)
     img = torch.randint(0, 256, (B, C, H, W, 3), dtype=torch.uint8, generator=g)
     w = torch.randn(C, Cout, 3, 7, 7, generator=g) / 147 ** 0.5
@@ -215,8 +216,8 @@ def test_conv1_u8_and_f32(B, C, H, W, Cout):
     exp = torch.stack([torch.relu(F.conv2d(xn[:, c], w[c].double(), None, 2, 3) * scale[c].double().view(1, -1, 1, 1)
                                   + bias[c].double().view(1, -1, 1, 1)) for c in range(C)])      # [C,B,Cout,Ho,Wo]
     d = dev()
-    got_u8 = ops.conv1(img.to(d), w.to(d), scale.to(d), bias.to(d)).permute(0, 1, 4, 2, 3)
-    got_f32 = ops.conv1(x.to(d), w.to(d), scale.to(d), bias.to(d)).permute(0, 1, 4, 2, 3)
+    got_u8 = ops.conv1(img.to(d), w.to(d), scale.to(d), bias.to(d), prec=prec).permute(0, 1, 4, 2, 3)
+    got_f32 = ops.conv1(x.to(d), w.to(d), scale.to(d), bias.to(d), prec=prec).permute(0, 1, 4, 2, 3)
     assert rel_err(got_u8, exp) < 2e-6
     assert rel_err(got_f32, exp) < 2e-6
     assert torch.equal(got_u8, got_f32)          # LUT path == arithmetic path, bit for bit
