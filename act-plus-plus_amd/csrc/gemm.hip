@@ -71,8 +71,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     // XCD-aware bijective remap: hardware deals consecutive block ids round-robin over the 8 XCDs; give each
     // XCD a contiguous run of tile ids so that neighbouring tiles (same A rows) share one L2.
     const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
+    const int splitk = p.splitk > 1 ? p.splitk : 1;
+    int bid = blockIdx.x, zz = blockIdx.z;
+    if (splitk == 1) {
+        // the remap runs over the FLATTENED (group, tile) space: an XCD then works through one group's tiles at a time
+        // (for the per-camera convolutions: one camera's weights per XCD instead of a slice of every camera at once --
+        // layer3/4 fetched 10-12x their operand bytes through the fabric before this)
+        const int total = nwg * (int)gridDim.z;
+        const int lin = blockIdx.z * gridDim.x + blockIdx.x;
+        const int xcd = lin & 7, q = total >> 3, r = total & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int flat = base + (lin >> 3);
+        zz = flat / nwg;
+        bid = flat - zz * nwg;
+    } else {
         const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
         bid = base + (bid >> 3);
@@ -89,9 +101,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     const int in_group = bid - group_id * width;
     const int m0 = (first_m + in_group % gsz) * BM;
     const int n0 = (in_group / gsz) * BN;
-    const int splitk = p.splitk > 1 ? p.splitk : 1;
-    const int split = blockIdx.z % splitk;
-    const int g = blockIdx.z / splitk;
+    const int split = zz % splitk;
+    const int g = zz / splitk;
     int64_t offA, offB, offC, offRes;
     if (p.groups_inner > 0) {
         const int g1 = g / p.groups_inner, g2 = g % p.groups_inner;

@@ -1,15 +1,40 @@
 #!/usr/bin/env python3
-"""Per-launch HBM traffic of the dominant kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), with the
-gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by exactly 2x; both counters
-are in KiB.  usage: pmc_traffic.py <fetch_counter_csv> <write_counter_csv> <kernel substring>"""
-import csv, sys
-def per_launch(path, counter, sub):
-    tot, n = 0.0, 0
+"""Per-launch HBM traffic of every kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), with the gfx950
+correction of MI355X_MICROARCH.md (FETCH_SIZE under-reports wide coalesced reads by exactly 2x; both counters are KiB).
+Kernel names are rewritten to the short names bench.py's in-library profiler uses, so that bench.py can look the
+dominant kernel up.  usage: pmc_traffic.py <fetch_counter_csv> <write_counter_csv> <out.json> [note]"""
+import csv, json, re, sys
+from collections import defaultdict
+
+
+def short_name(n):
+    n = re.sub(r"^void\s+", "", n)
+    n = n.replace("(anonymous namespace)::", "")
+    n = re.sub(r"\(.*\)$", "", n).strip()
+    n = n.replace(" ", "")
+    m = re.match(r"gemm_f32_kernel<(\d+),(\d+),(\d+),(\d+),(\d+),(\d+),(\d+),(\d+)>", n)
+    if m:       # <BM,BN,WM,WN,AMODE,BMODE,PREC,BSPLIT> -> the profiler's name
+        g = m.groups()
+        return "gemm_%s_kernel<%s>" % ("f16x3" if g[6] == "1" else "f32", ",".join(g[:6]))
+    return n
+
+
+def collect(path, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and sub in r["Kernel_Name"]:
-            tot += float(r["Counter_Value"]); n += 1
-    return tot / max(n, 1), n
-f, nf = per_launch(sys.argv[1], "FETCH_SIZE", sys.argv[3])
-w, nw = per_launch(sys.argv[2], "WRITE_SIZE", sys.argv[3])
-print({"kernel": sys.argv[3], "launches": nf, "fetch_bytes_per_launch_corrected": f * 1024 * 2, "write_bytes_per_launch": w * 1024,
-       "traffic_bytes_per_launch": f * 2048 + w * 1024})
+        if r["Counter_Name"] == counter:
+            k = short_name(r["Kernel_Name"])
+            tot[k] += float(r["Counter_Value"]); cnt[k] += 1
+    return tot, cnt
+
+
+ft, fc = collect(sys.argv[1], "FETCH_SIZE")
+wt, wc = collect(sys.argv[2], "WRITE_SIZE")
+out = {"note": sys.argv[4] if len(sys.argv) > 4 else "", "kernels": {}}
+for k in ft:
+    f = ft[k] / max(fc[k], 1) * 1024 * 2
+    w = wt.get(k, 0.0) / max(wc.get(k, 0), 1) * 1024
+    out["kernels"][k] = {"launches": fc[k], "fetch_bytes_per_launch": f, "write_bytes_per_launch": w,
+                         "traffic_bytes_per_launch": f + w}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print("kernels:", len(out["kernels"]))
