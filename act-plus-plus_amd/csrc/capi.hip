@@ -126,6 +126,11 @@ int actmi_op_split16(const float* src, float* dst, int64_t nfloats, float scale,
     return rc == 0 ? 0 : ACTMI_E_INVALID;
 }
 
+int actmi_op_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, void* stream) {
+    g_op_error.clear();
+    return launch_pow2_scale(x, ld, M, N, out, S(stream)) == 0 ? 0 : ACTMI_E_LAUNCH;
+}
+
 int actmi_op_attention(const actmi_attn_desc* d, void* stream) {
     if (!d) return ACTMI_E_INVALID;
     g_op_error.clear();

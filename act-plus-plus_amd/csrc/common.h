@@ -101,6 +101,8 @@ int launch_small_linear_wgrad(const float* dy, int64_t lddy, const float* x, int
                               hipStream_t st);
 int launch_cvae_maps(int* map, uint8_t* kpm, const uint8_t* is_pad, int B, int Q, hipStream_t st);
 int launch_axpy(float* dst, const float* src, int64_t n, hipStream_t st);
+int launch_scale(float* x, int64_t n, float s, hipStream_t st);
+int launch_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, hipStream_t st);
 int launch_split16(const float* src, float* dst, int64_t nfloats, float scale, hipStream_t st);
 int launch_dropout_bwd(const float* dy, float* dz, uint64_t seed, float p, int64_t n, hipStream_t st);
 int launch_attn_drop(const float* P, float* Pd, uint64_t seed, float p, int G, int Nq, int Nk, int ldp, hipStream_t st);

@@ -59,6 +59,11 @@ struct TrainState {
     // general decoder self-attention path (dropout > 0)
     float drop_p = 0.f;
     uint64_t drop_seed = 0;
+    bool grads_dirty = false;
+    float* scale_slots = nullptr;      // [SCALE_SLOTS][2]: device-computed operand scales of the f16x3 backward GEMMs
+    int scale_next = 0;
+    const float* amax_key_ptr = nullptr; int64_t amax_key_ld = 0; int amax_key_m = 0, amax_key_n = 0;   // one-shot reuse
+    const float* amax_key_slot = nullptr;          // the gradient arena holds gradients of an earlier backward (no zero_grad since)
     float *qkd = nullptr, *sO = nullptr, *lse_s = nullptr, *saB = nullptr, *T1B = nullptr, *dqB = nullptr, *gT1 = nullptr,
           *dsaB = nullptr, *dqkB = nullptr, *dvB = nullptr, *dqk_d = nullptr, *tmpQD = nullptr;
     // backward scratch

@@ -361,6 +361,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     // stores into the (hi, lo) planes of its contraction group, at half (chunk & 1) of the 16-byte unit.
     // MASKED = false: no zero-fill selects (legal when K is a multiple of the K tile and the operand is plain row-major:
     // rows beyond M / N are staged from a valid clamped address and only ever reach outputs that are not stored).
+    // optional power-of-two operand pre-scales (keep small operands' lo pieces out of the fp16 subnormals; undone through
+    // alpha).  Only the MASKED flavour applies them; the host never selects the unmasked one when they are set.
+    // a *_scale_dev pointer supplies a scale computed on the device (actmi_op_pow2_scale: power of two that brings the
+    // operand's largest magnitude to [2^13, 2^14)) -- the backward pass uses it for gradient operands, whose magnitudes
+    // span many decades across the network
+    const float pre_a = (p.a_scale != 0.f ? p.a_scale : 1.f) * (p.a_scale_dev ? *p.a_scale_dev : 1.f);
+    const float pre_b = BSPLIT ? 1.f : (p.b_scale != 0.f ? p.b_scale : 1.f) * (p.b_scale_dev ? *p.b_scale_dev : 1.f);
     auto store16 = [&](int stage, auto& R, auto maskedc) {
         constexpr bool MASKED = decltype(maskedc)::value;
         f32x4* sa = smem + stage * STAGE;
@@ -371,7 +378,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
             if (a_kg < NPL) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 v = {R.ra[0][i], R.ra[1][i], R.ra[2][i], R.ra[3][i]};
+                    const f32x4 v = f32x4{R.ra[0][i], R.ra[1][i], R.ra[2][i], R.ra[3][i]} * pre_a;
                     uint2 hi, lo;
                     split16(v, hi, lo);
                     const int row = a_og * 4 + i;
@@ -385,6 +392,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
                 f32x4 v = R.ra[i];
                 if (AMODE == A_NADD) { if (use_add) v += R.rx[i]; }
                 if (AMODE == A_CONV || (MASKED && AMODE != A_DGRAD)) v = R.ra_ok[i] ? v : zero4;
+                if (MASKED) v *= pre_a;
                 uint2 hi, lo;
                 split16(v, hi, lo);
                 const int row = srow + RPP * i;
@@ -395,7 +403,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
         if (BMODE == B_N) {
 #pragma unroll
             for (int i = 0; i < NLB; ++i) {
-                const f32x4 v = (!MASKED || R.rb_ok[i]) ? R.rb[i] : zero4;
+                f32x4 v = (!MASKED || R.rb_ok[i]) ? R.rb[i] : zero4;
+                if (MASKED && !BSPLIT) v *= pre_b;
                 uint2 hi, lo;
                 if (BSPLIT) {     // weights split ahead of time: each 16-byte group is {4 hi halfs, 4 lo halfs}
                     const uint4 u = __builtin_bit_cast(uint4, v);
@@ -410,7 +419,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
             if (b_kg < NPL) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 v = {R.rb[0][i], R.rb[1][i], R.rb[2][i], R.rb[3][i]};
+                    const f32x4 v = f32x4{R.rb[0][i], R.rb[1][i], R.rb[2][i], R.rb[3][i]} * pre_b;
                     uint2 hi, lo;
                     split16(v, hi, lo);
                     const int row = b_og * 4 + i;
@@ -541,7 +550,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
             }
         };
         // block-uniform choice of the loop flavour
-        if ((AMODE == A_N || AMODE == A_NADD || AMODE == A_CONV) && BMODE == B_N && (p.K % BK) == 0) run(std::false_type{});
+        if ((AMODE == A_N || AMODE == A_NADD || AMODE == A_CONV) && BMODE == B_N && (p.K % BK) == 0 && pre_a == 1.f && pre_b == 1.f)
+            run(std::false_type{});
         else run(std::true_type{});
     } else {
     load_tile(kt_begin, R0);
@@ -627,7 +637,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     float* C = p.C + offC;
     float* C2 = p.C2 ? p.C2 + (int64_t)g * p.gC2out : nullptr;
     // a pre-split B image may carry a power-of-two scale (keeps small weights' lo pieces out of fp16 subnormals)
-    const float alpha = (p.alpha != 0.f ? p.alpha : 1.f) * ((BSPLIT && p.b_scale != 0.f) ? 1.f / p.b_scale : 1.f);
+    float alpha = p.alpha != 0.f ? p.alpha : 1.f;
+    if (PREC == PREC_F16X3) {
+        if (p.b_scale != 0.f) alpha /= p.b_scale;
+        if (p.a_scale != 0.f) alpha /= p.a_scale;
+        if (p.a_scale_dev) alpha /= *p.a_scale_dev;
+        if (!BSPLIT && p.b_scale_dev) alpha /= *p.b_scale_dev;
+    }
     const bool has_res = res != nullptr, has_mask = mask != nullptr, has_map = p.rowmap != nullptr;
     const float drop_scale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
     // Fast epilogue for the forward-pass cases (bias / FrozenBN affine, optional same-shape residual, optional ReLU): the

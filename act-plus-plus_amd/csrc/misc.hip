@@ -241,6 +241,57 @@ int launch_split16(const float* src, float* dst, int64_t nfloats, float scale, h
     return (int)hipGetLastError();
 }
 
+__global__ void scale_kernel(float* __restrict__ x, int64_t n4, int64_t n, float s) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) {
+        actmi_f32x4* p = reinterpret_cast<actmi_f32x4*>(x) + i;
+        *p = *p * s;
+    } else if (i == n4) {
+        for (int64_t j = n4 * 4; j < n; ++j) x[j] *= s;
+    }
+}
+
+// max |x| over an M x N matrix (row stride ld) as the bits of a non-negative float (monotone as unsigned), then the
+// power-of-two scale derived from it
+__global__ void amax_kernel(const float* __restrict__ x, int64_t ld, int M, int N, unsigned* __restrict__ bits) {
+    const int64_t total = (int64_t)M * N;
+    unsigned m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / N, c = i - r * N;
+        m = max(m, __float_as_uint(x[r * ld + c]) & 0x7fffffffu);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(bits, m);
+}
+
+__global__ void pow2_scale_kernel(unsigned* __restrict__ bits, float* __restrict__ out) {
+    const unsigned b = *bits;
+    const int e = (int)(b >> 23);                      // biased exponent of max|x|
+    float s = 1.f;
+    if (b != 0 && e != 255) s = ldexpf(1.f, 13 - (e - 127));     // 2^e' <= max < 2^(e'+1)  ->  max * s in [2^13, 2^14)
+    *out = s;
+    *bits = 0;                                         // re-arm the slot
+}
+
+int launch_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, hipStream_t st) {
+    // the word after the scale holds the running max bits (zero between uses)
+    unsigned* bits = reinterpret_cast<unsigned*>(out + 1);
+    const int64_t total = (int64_t)M * N;
+    int blocks = (int)((total + 256 * 16 - 1) / (256 * 16));
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, st, x, ld, M, N, bits);
+    hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, st, bits, out);
+    return (int)hipGetLastError();
+}
+
+int launch_scale(float* x, int64_t n, float s, hipStream_t st) {
+    if (n <= 0) return 0;
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n4 + 1 + 255) / 256)), dim3(256), 0, st, x, n4, n, s);
+    return (int)hipGetLastError();
+}
+
 int launch_axpy(float* dst, const float* src, int64_t n, hipStream_t st) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(axpy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, src, n);

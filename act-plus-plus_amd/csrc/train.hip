@@ -52,6 +52,35 @@ GemmArgs G0() {
     return a;
 }
 
+// every GEMM of the training step: forward operand forms go through ctx_gemm (handle precision + pre-split weights where
+// B is a parameter), the backward forms take the handle precision directly
+int tgemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
+    if (a.ta == 0 && a.tb == 0 && a.mode != 2) return ctx_gemm(ctx, a, st);
+    a.prec = ctx->gemm_prec;
+    return launch_gemm(a, st, &ctx->err);
+}
+
+// Gradient operands of the f16x3 backward GEMMs get a power-of-two scale computed on the device from their largest
+// magnitude (gradients range from ~1e-7 at the stem to ~1e2 in the CVAE encoder: no single loss scale fits the fp16
+// range).  A dgrad / wgrad pair on the same dY computes it once (one-shot reuse, cleared by any other request).
+constexpr int SCALE_SLOTS = 1024;
+const float* dyn_scale(actmi_ctx* ctx, const float* x, int64_t ld, int M, int N, hipStream_t st, bool keep = false) {
+    if (ctx->gemm_prec != ACTMI_PREC_F16X3) return nullptr;
+    TrainState& T = *ctx->train;
+    if (T.amax_key_ptr == x && T.amax_key_ld == ld && T.amax_key_m == M && T.amax_key_n == N) {
+        const float* slot = T.amax_key_slot;
+        T.amax_key_ptr = nullptr;
+        return slot;
+    }
+    float* slot = T.scale_slots + 2 * (T.scale_next++ % SCALE_SLOTS);
+    if (launch_pow2_scale(x, ld, M, N, slot, st) != 0) return nullptr;
+    T.amax_key_ptr = keep ? x : nullptr; T.amax_key_ld = ld; T.amax_key_m = M; T.amax_key_n = N; T.amax_key_slot = slot;
+    return slot;
+}
+
+// power-of-two pre-scale for weight operands of the backward GEMMs (f16x3: keeps lo pieces of ~1e-2 weights normal)
+constexpr float WGT_PRESCALE = 256.f;
+
 int pick_splitk(int M, int N, int groups, int K) {
     const long tiles = (long)((M + 127) / 128) * ((N + 63) / 64) * groups;
     long s = 1024 / (tiles > 0 ? tiles : 1);
@@ -68,7 +97,7 @@ int lin_fwd(actmi_ctx* ctx, const float* x, int64_t ldx, int M, int K, const flo
     GemmArgs a = G0();
     a.A = x; a.lda = ldx; a.M = M; a.K = K; a.N = N; a.Bw = W; a.ldb = K; a.bias = b; a.C = y; a.ldc = ldy;
     a.res = res; a.ldres = ldy; a.relu = relu; a.drop_p = drop_p; a.drop_seed = drop_seed;
-    return launch_gemm(a, st, &ctx->err);
+    return tgemm(ctx, a, st);
 }
 
 // dx[M][K] = dy[M][N] W[N][K] (+res) (masked by mask>0)
@@ -77,7 +106,9 @@ int lin_dgrad(actmi_ctx* ctx, const float* dy, int64_t lddy, int M, int N, const
     GemmArgs a = G0();
     a.A = dy; a.lda = lddy; a.M = M; a.K = N; a.N = K; a.Bw = W; a.ldb = K; a.tb = 1; a.C = dx; a.ldc = lddx;
     a.res = res; a.ldres = lddx; a.mask = mask; a.ldmask = lddx; a.alpha = alpha;
-    return launch_gemm(a, st, &ctx->err);
+    a.b_scale = WGT_PRESCALE;
+    a.a_scale_dev = dyn_scale(ctx, dy, lddy, M, N, st, true);
+    return tgemm(ctx, a, st);
 }
 
 // dropout sites of one layer: 0 attention weights, 1 after the attention out-projection, 2 FFN hidden, 3 after linear2
@@ -96,7 +127,8 @@ int lin_wgrad(actmi_ctx* ctx, const float* dy, int64_t lddy, int M, int N, const
         a.C = dW; a.ldc = K;
         a.splitk = pick_splitk(N, K, 1, M);
         if (a.splitk <= 1) { a.splitk = 0; a.res = dW; a.ldres = K; }
-        CHK(launch_gemm(a, st, &ctx->err));
+        a.a_scale_dev = dyn_scale(ctx, dy, lddy, M, N, st);
+        CHK(tgemm(ctx, a, st));
     }
     if (db) CHK(launch_colsum(dy, lddy, db, M, N, st));
     return 0;
@@ -126,7 +158,7 @@ int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
     s.A = t.Q; s.lda = t.q_rs; s.M = t.Nq; s.K = t.HD; s.Bw = t.K; s.ldb = t.k_rs; s.N = t.Nk; s.C = P; s.ldc = ldp;
     s.alpha = scale; s.groups = G; s.groups_inner = t.H;
     s.gA = t.q_bs; s.gA2 = t.HD; s.gB = t.k_bs; s.gB2 = t.HD; s.gC = pg * t.H; s.gC2 = pg;
-    CHK(launch_gemm(s, st, &ctx->err));
+    CHK(tgemm(ctx, s, st));
     CHK(launch_attn_probs(P, t.lse, t.kpm, t.kpm_bs, G, t.H, t.Nq, t.Nk, ldp, st));
     CHK(launch_attn_delta(t.dO, t.O, T.delta, t.B, t.H, t.Nq, t.HD, st));
     // dV[key][d] = sum_q Pd[q][key] dO[q][d]   (Pd = dropped weights; staged in the dP buffer before dP overwrites it)
@@ -139,13 +171,17 @@ int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
     v.A = Pv; v.lda = ldp; v.ta = 1; v.M = t.Nk; v.K = t.Nq; v.Bw = t.dO; v.ldb = D; v.tb = 1; v.N = t.HD;
     v.C = t.dV; v.ldc = t.dv_rs; v.groups = G; v.groups_inner = t.H;
     v.gA = pg * t.H; v.gA2 = pg; v.gB = (int64_t)t.Nq * D; v.gB2 = t.HD; v.gC = t.dv_bs; v.gC2 = t.HD;
-    CHK(launch_gemm(v, st, &ctx->err));
+    v.a_scale = 256.f;          // probabilities (<= 1/(1-p)) are mostly ~1/Nk
+    const float* dO_sc = dyn_scale(ctx, t.dO, D, t.B * t.Nq, D, st);
+    v.b_scale_dev = dO_sc;
+    CHK(tgemm(ctx, v, st));
     // dP = dO V^T
     GemmArgs d = G0();
     d.A = t.dO; d.lda = D; d.M = t.Nq; d.K = t.HD; d.Bw = t.V; d.ldb = t.v_rs; d.N = t.Nk; d.C = dP; d.ldc = ldp;
     d.groups = G; d.groups_inner = t.H;
     d.gA = (int64_t)t.Nq * D; d.gA2 = t.HD; d.gB = t.v_bs; d.gB2 = t.HD; d.gC = pg * t.H; d.gC2 = pg;
-    CHK(launch_gemm(d, st, &ctx->err));
+    d.a_scale_dev = dO_sc;
+    CHK(tgemm(ctx, d, st));
     // dS = P * (dP - delta) * scale   (in place of dP; with dropout dP = dPd * mask / (1-p))
     if (t.drop_p > 0.f) CHK(launch_attn_ds_drop(P, dP, T.delta, scale, t.drop_seed, t.drop_p, G, t.Nq, t.Nk, ldp, st));
     else CHK(launch_attn_ds(P, dP, T.delta, scale, G, t.Nq, t.Nk, ldp, st));
@@ -154,13 +190,16 @@ int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
     q.A = dP; q.lda = ldp; q.M = t.Nq; q.K = t.Nk; q.Bw = t.K; q.ldb = t.k_rs; q.tb = 1; q.N = t.HD;
     q.C = t.dQ; q.ldc = t.dq_rs; q.groups = G; q.groups_inner = t.H;
     q.gA = pg * t.H; q.gA2 = pg; q.gB = t.k_bs; q.gB2 = t.HD; q.gC = t.dq_bs; q.gC2 = t.HD;
-    CHK(launch_gemm(q, st, &ctx->err));
+    const float* dS_sc = dyn_scale(ctx, dP, ldp, G * t.Nq, t.Nk, st);
+    q.a_scale_dev = dS_sc;
+    CHK(tgemm(ctx, q, st));
     // dK[key][d] = sum_q dS[q][key] Q[q][d]
     GemmArgs k = G0();
     k.A = dP; k.lda = ldp; k.ta = 1; k.M = t.Nk; k.K = t.Nq; k.Bw = t.Q; k.ldb = t.q_rs; k.tb = 1; k.N = t.HD;
     k.C = t.dK; k.ldc = t.dk_rs; k.groups = G; k.groups_inner = t.H;
     k.gA = pg * t.H; k.gA2 = pg; k.gB = t.q_bs; k.gB2 = t.HD; k.gC = t.dk_bs; k.gC2 = t.HD;
-    CHK(launch_gemm(k, st, &ctx->err));
+    k.a_scale_dev = dS_sc;
+    CHK(tgemm(ctx, k, st));
     return 0;
 }
 
@@ -173,7 +212,7 @@ int enc_fwd(actmi_ctx* ctx, const EncW& w, EncSave& s, float* out, const float* 
     qkv.A = s.x_in; qkv.lda = D; qkv.M = M; qkv.K = D; qkv.Bw = w.attn.in_w; qkv.ldb = D; qkv.N = 3 * D;
     qkv.bias = w.attn.in_b; qkv.C = s.QKV; qkv.ldc = 3 * D;
     qkv.A_add = pos; qkv.ld_add = D; qkv.add_mod = n; qkv.add_ncols = 2 * D;
-    CHK(launch_gemm(qkv, st, &ctx->err));
+    CHK(tgemm(ctx, qkv, st));
     AttnArgs at;
     memset(&at, 0, sizeof(at));
     at.Q = s.QKV; at.q_bs = (int64_t)n * 3 * D; at.q_rs = 3 * D;
@@ -183,6 +222,7 @@ int enc_fwd(actmi_ctx* ctx, const EncW& w, EncSave& s, float* out, const float* 
     at.kpm = kpm; at.kpm_bs = n; at.lse = s.lse;
     at.B = B; at.H = g.nheads; at.Nq = n; at.Nk = n; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
     at.ws = ctx->attn_ws; at.ws_floats = ctx->attn_ws_floats;
+    at.prec = ctx->gemm_prec;
     at.drop_p = dr.p; at.drop_seed = dr.s(0);
     CHK(launch_attention(at, st, &ctx->err));
     CHK(lin_fwd(ctx, s.ATT, D, M, D, w.attn.out_w, D, w.attn.out_b, s.Y1, D, s.x_in, 0, st, dr.p, dr.s(1)));
@@ -240,7 +280,9 @@ int enc_bwd(actmi_ctx* ctx, const EncW& w, const EncSave& s, const float* dOut, 
         GemmArgs a = G0();
         a.A = gQKV; a.lda = 3 * D; a.a_rowmap = T.pos_rows; a.M = 2 * B; a.K = 2 * D; a.Bw = w.attn.in_w; a.ldb = D; a.tb = 1;
         a.N = D; a.C = T.tmp2BD; a.ldc = D;
-        CHK(launch_gemm(a, st, &ctx->err));
+        a.b_scale = WGT_PRESCALE;
+        a.a_scale_dev = dyn_scale(ctx, gQKV, 3 * D, M, 2 * D, st);
+        CHK(tgemm(ctx, a, st));
         CHK(launch_sum_batch(T.tmp2BD, 2 * D, D, dpos2, B, 2, D, 1, st));
     }
     return 0;
@@ -258,7 +300,8 @@ int conv_wgrad(actmi_ctx* ctx, const ConvLayer& cl, int li, const float* dys, co
     a.gA = (int64_t)B * cl.Ho * cl.Wo * cl.cout; a.gB = (int64_t)B * cl.H * cl.W * cl.cin; a.gC = (int64_t)cl.cout * cl.K;
     a.splitk = pick_splitk(cl.cout, cl.K, C, a.K);
     if (a.splitk <= 1) { a.splitk = 0; a.res = a.C; a.ldres = cl.K; a.gRes = a.gC; }
-    return launch_gemm(a, st, &ctx->err);
+    a.a_scale_dev = dyn_scale(ctx, dys, cl.cout, C * B * cl.Ho * cl.Wo, cl.cout, st);
+    return tgemm(ctx, a, st);
 }
 
 // dx[C][B][H][W][cin] = dgrad(dys) (+res) , then masked by (mask > 0) and multiplied by scale[cin] (previous BN)
@@ -274,7 +317,9 @@ int conv_dgrad(actmi_ctx* ctx, const ConvLayer& cl, int li, const float* dys, fl
     a.gA = (int64_t)B * cl.Ho * cl.Wo * cl.cout; a.gB = (int64_t)cl.cin * a.K; a.gC = (int64_t)a.M * cl.cin;
     a.res = res; a.ldres = cl.cin; a.gRes = a.gC; a.mask = mask; a.ldmask = cl.cin; a.gMask = a.gC;
     a.scale = scale; a.gSB = cl.cin;
-    return launch_gemm(a, st, &ctx->err);
+    a.b_scale = WGT_PRESCALE;
+    a.a_scale_dev = dyn_scale(ctx, dys, cl.cout, C * B * cl.Ho * cl.Wo, cl.cout, st, true);
+    return tgemm(ctx, a, st);
 }
 
 }  // namespace
@@ -333,6 +378,8 @@ int train_create(actmi_ctx* ctx) {
         T.conv_gw.push_back(gw); T.conv_wd.push_back(wd);
     }
     TA(T.conv1_gw, (int64_t)C * w0 * 196);
+    TA(T.scale_slots, 2 * SCALE_SLOTS);
+    if (hipMemset(T.scale_slots, 0, 2 * SCALE_SLOTS * 4) != hipSuccess) { ctx->err = "hipMemset failed"; return ACTMI_E_LAUNCH; }
     // transformer saves
     auto alloc_enc = [&](std::vector<EncSave>& v, int n, float* first_in) -> int {
         const int64_t M = (int64_t)B * n;
@@ -419,7 +466,7 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
         GemmArgs ap = G0();
         ap.A = T.actions; ap.lda = A; ap.M = B * Q; ap.K = A; ap.Bw = ctx->P("encoder_action_proj.weight"); ap.ldb = A; ap.N = D;
         ap.bias = ctx->P("encoder_action_proj.bias"); ap.C = T.Xc; ap.ldc = D; ap.rowmap = T.cmap;
-        CHK(launch_gemm(ap, st, &ctx->err));
+        CHK(tgemm(ctx, ap, st));
         for (int l = 0; l < g.enc_layers; ++l) {
             float* out = (l + 1 < g.enc_layers) ? T.cv[l + 1].x_in : T.cv_out;
             CHK(enc_fwd(ctx, ctx->cvae[l], T.cv[l], out, ctx->P("pos_table"), B, n, T.ckpm, Drop{dropout_p, dropout_seed, (uint32_t)(8 * l)}, st));
@@ -440,6 +487,7 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
         c1.image = image; c1.fmt = fmt; c1.lut = ctx->lut; c1.w = ctx->conv1_w; c1.scale = ctx->conv1_scale;
         c1.bias = ctx->conv1_bias; c1.out = ctx->act1; c1.B = B; c1.C = C; c1.H = g.image_h; c1.W = g.image_w;
         c1.Ho = ctx->H1; c1.Wo = ctx->W1; c1.Cout = w0;
+        c1.prec = ctx->gemm_prec;
         CHK(launch_conv1(c1, st, &ctx->err));
         CHK(launch_maxpool(ctx->act1, T.pool, C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
     }
@@ -453,7 +501,7 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
         a.C = out; a.ldc = cl.cout; a.groups = C;
         a.gA = (int64_t)B * cl.H * cl.W * cl.cin; a.gB = (int64_t)cl.cout * cl.K; a.gSB = cl.cout;
         a.gC = (int64_t)a.M * cl.cout; a.gRes = a.gC;
-        return launch_gemm(a, st, &ctx->err);
+        return tgemm(ctx, a, st);
     };
     const float* x = T.pool;
     for (auto& bs : T.blocks) {
@@ -474,7 +522,7 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
         GemmArgs ip = G0();
         ip.A = x; ip.lda = 8 * w0; ip.M = C * B * ctx->P_; ip.K = 8 * w0; ip.Bw = ctx->P("input_proj.weight"); ip.ldb = 8 * w0;
         ip.N = D; ip.bias = ctx->P("input_proj.bias"); ip.C = ctx->X; ip.ldc = D; ip.rowmap = ctx->rowmap;
-        CHK(launch_gemm(ip, st, &ctx->err));
+        CHK(tgemm(ctx, ip, st));
     }
     CHK(launch_small_linear(qpos, S, ctx->P("input_proj_robot_state.weight"), ctx->P("input_proj_robot_state.bias"),
                             ctx->X + D, (int64_t)N * D, B, D, S, st));
@@ -515,14 +563,14 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
         GemmArgs qg = G0();
         qg.A = T.T1B; qg.lda = D; qg.M = M; qg.K = D; qg.Bw = d.cross.in_w; qg.ldb = D; qg.N = D; qg.bias = d.cross.in_b;
         qg.C = T.dqB; qg.ldc = D; qg.A_add = ctx->P("query_embed.weight"); qg.ld_add = D; qg.add_mod = Q; qg.add_ncols = D;
-        CHK(launch_gemm(qg, st, &ctx->err));
+        CHK(tgemm(ctx, qg, st));
     }
     {
         GemmArgs kv = G0();
         kv.A = T.mem; kv.lda = D; kv.M = B * N; kv.K = D; kv.Bw = d.cross.in_w + (int64_t)D * D; kv.ldb = D; kv.N = 2 * D;
         kv.bias = d.cross.in_b + D; kv.C = T.KV; kv.ldc = 2 * D;
         kv.A_add = ctx->pos_tokens; kv.ld_add = D; kv.add_mod = N; kv.add_ncols = D;
-        CHK(launch_gemm(kv, st, &ctx->err));
+        CHK(tgemm(ctx, kv, st));
         AttnArgs at;
         memset(&at, 0, sizeof(at));
         at.Q = gen ? T.dqB : T.dq; at.q_bs = gen ? (int64_t)Q * D : 0; at.q_rs = D;
@@ -531,6 +579,8 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
         at.O = T.Oc; at.o_bs = (int64_t)Q * D; at.o_rs = D; at.lse = T.lse_c;
         at.B = B; at.H = g.nheads; at.Nq = Q; at.Nk = N; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
         at.ws = ctx->attn_ws; at.ws_floats = ctx->attn_ws_floats;
+        at.prec = ctx->gemm_prec;
+    at.prec = ctx->gemm_prec;
         at.drop_p = dropout_p; at.drop_seed = dr_dec.s(4);
         CHK(launch_attention(at, st, &ctx->err));
     }
@@ -539,7 +589,7 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
         op.A = T.Oc; op.lda = D; op.M = M; op.K = D; op.Bw = d.cross.out_w; op.ldb = D; op.N = D; op.bias = d.cross.out_b;
         op.C = T.Y2pre; op.ldc = D; op.res = gen ? T.T1B : T.t1; op.ldres = D; op.res_mod = gen ? 0 : 1;
         op.drop_p = dropout_p; op.drop_seed = dr_dec.s(5);
-        CHK(launch_gemm(op, st, &ctx->err));
+        CHK(tgemm(ctx, op, st));
     }
     CHK(launch_layernorm(T.Y2pre, nullptr, 0, d.n2w, d.n2b, nullptr, nullptr, T.T2, M, D, 1e-5f, st, &ctx->err));
     CHK(lin_fwd(ctx, T.T2, D, M, D, d.l1w, F, d.l1b, T.Hd, F, nullptr, 1, st, dropout_p, dr_dec.s(2)));
@@ -572,6 +622,20 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
     const int M = B * Q;
     const DecW& d = ctx->dec[0];
 
+    // ---- optional global loss scale (f16x3, ACTMI_LOSS_SCALE_LOG2; tuning aid): the seed is multiplied by a power of two
+    // and the finished gradient arena multiplied back (both exact); gradients already in the arena (accumulation
+    // without zero_grad) are carried through the same scale.  Off by default -- see dyn_scale.
+    T.amax_key_ptr = nullptr;
+    float LS = 1.f;
+    if (ctx->gemm_prec == ACTMI_PREC_F16X3) {
+        static const char* ls_env = getenv("ACTMI_LOSS_SCALE_LOG2");
+        int e = ls_env ? atoi(ls_env) : 0;         // off by default: operands are scaled individually (dyn_scale)
+        if (e < 0) e = 0;
+        if (e > 24) e = 24;
+        LS = ldexpf(1.f, e);
+    }
+    if (LS != 1.f && T.grads_dirty) CHK(launch_scale(T.gbase, ctx->ptotal, LS, st));
+    loss_scale *= LS;
     // ---- loss -> a_hat -> heads
     float* d_ahat = T.gQKV;                 // scratch [M][A]
     CHK(launch_l1_bwd(T.a_hat, T.actions, T.is_pad, d_ahat, B, Q, A, loss_scale, st));
@@ -684,7 +748,9 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
         GemmArgs a = G0();
         a.A = dKV; a.lda = 2 * D; a.a_rowmap = T.pos_rows; a.M = 2 * B; a.K = D; a.Bw = d.cross.in_w + (int64_t)D * D; a.ldb = D;
         a.tb = 1; a.N = D; a.C = T.tmp2BD; a.ldc = D;
-        CHK(launch_gemm(a, st, &ctx->err));
+        a.b_scale = WGT_PRESCALE;
+        a.a_scale_dev = dyn_scale(ctx, dKV, 2 * D, B * N, D, st);
+        CHK(tgemm(ctx, a, st));
         CHK(launch_sum_batch(T.tmp2BD, 2 * D, D, dpos2, B, 2, D, 1, st));
     }
     // ---- encoder layers, last to first.  dOut lives in gB; each layer returns its dIn in gB again.
@@ -756,7 +822,8 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
         a.gA = (int64_t)B * ctx->H1 * ctx->W1 * w0; a.gB = (int64_t)B * g.image_h * g.image_w * 4; a.gC = (int64_t)w0 * 196;
         a.splitk = pick_splitk(w0, 196, C, a.K);
         if (a.splitk <= 1) { a.splitk = 0; a.res = a.C; a.ldres = 196; a.gRes = a.gC; }
-        CHK(launch_gemm(a, st, &ctx->err));
+        a.a_scale_dev = dyn_scale(ctx, T.g_act1, w0, C * B * ctx->H1 * ctx->W1, w0, st);
+        CHK(tgemm(ctx, a, st));
     }
     // packed conv gradients -> OIHW state_dict gradients
     for (int cam = 0; cam < C; ++cam) {
@@ -790,6 +857,8 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
         CHK(lin_wgrad(ctx, T.dXg, D, B * Q, D, T.actions, A, A, nullptr, 0, GP("encoder_action_proj.weight"),
                       GP("encoder_action_proj.bias"), st));
     }
+    if (LS != 1.f) CHK(launch_scale(T.gbase, ctx->ptotal, 1.f / LS, st));
+    T.grads_dirty = true;
     T.have_forward = false;
     return 0;
 }
@@ -797,6 +866,7 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
 int train_zero_grad(actmi_ctx* ctx, hipStream_t st) {
     if (!ctx->train) { ctx->err = "handle was created without enable_training"; return ACTMI_E_STATE; }
     HIPCHK(hipMemsetAsync(ctx->train->gbase, 0, (size_t)ctx->ptotal * 4, st));
+    ctx->train->grads_dirty = false;
     return 0;
 }
 

@@ -113,8 +113,16 @@ typedef struct actmi_gemm_desc {
     /* f16x3 only: Bw already holds split weights (actmi_op_split16: every aligned group of 4 floats replaced by
      * 4 hi halfs + 4 lo halfs, same addressing as the fp32 matrix) */
     int32_t b_split;
-    /* with b_split: the image was built from Bw * b_scale (a power of two, see actmi_op_split16); 0 means 1 */
+    /* f16x3 only: power-of-two operand pre-scales, undone through alpha (0 means 1).  With b_split, b_scale says what the
+     * image was built with (actmi_op_split16); otherwise the kernel multiplies the operand on its way into LDS.  Use them
+     * for operands whose typical magnitude is below ~1e-2 (weights: 256) so that the lo pieces stay normal fp16 numbers;
+     * |x| * scale must stay below 65504. */
     float b_scale;
+    float a_scale;
+    /* f16x3 only: optional device-resident power-of-two scales (one float each, see actmi_op_pow2_scale), multiplied
+     * with a_scale / b_scale; read by the kernel, so they can be produced on the same stream just before the launch */
+    const float* a_scale_dev;
+    const float* b_scale_dev;
 } actmi_gemm_desc;
 
 /* Multi-head attention descriptor: softmax(scale * q k^T [+ key padding mask]) v per (batch, head).
@@ -189,6 +197,9 @@ int actmi_op_gemm(const actmi_gemm_desc* d, void* stream);
  * alias).  scale must be a power of two with |src| * scale < 65504; 256 suits network weights: pieces of values
  * around 1e-2 then stay normal fp16 numbers (full 22-bit split) instead of subnormals. */
 int actmi_op_split16(const float* src, float* dst, int64_t nfloats, float scale, void* stream);
+/* out[0] = the power of two s with max|x| * s in [2^13, 2^14) over the M x N matrix x (row stride ld); 1 if x is all
+ * zero or not finite.  out[1] is scratch and must be zero before the first use (the op leaves it zero).  For actmi_gemm_desc.a_scale_dev / b_scale_dev. */
+int actmi_op_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, void* stream);
 int actmi_op_attention(const actmi_attn_desc* d, void* stream);
 int actmi_op_layernorm(const float* x, const float* res, int res_mod, const float* w, const float* b, const float* w2,
                        const float* b2, float* y, int M, int D, float eps, void* stream);
