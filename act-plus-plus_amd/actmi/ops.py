@@ -23,8 +23,20 @@ def split16(w, scale=1.0):
     return out
 
 
+def pow2_scale(x):
+    """[scale, scratch]: scale = the power of two that brings max|x| into [2^13, 2^14) (device-side, no host sync);
+    pass the tensor as gemm(..., a_scale_dev=) / b_scale_dev= for operands far from the fp16 range."""
+    lib = L.load()
+    assert x.dim() == 2 and x.stride(1) == 1
+    out = torch.zeros(2, dtype=torch.float32, device=x.device)
+    L.check(lib.actmi_op_pow2_scale(_p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), L.current_stream_ptr()), None,
+            "op_pow2_scale")
+    return out
+
+
 def gemm(A, W, bias=None, scale=None, res=None, res_mod=0, relu=False, a_add=None, add_mod=0, add_ncols=0, rowmap=None,
-         out=None, out_rows=None, drop_p=0.0, drop_seed=0, prec=None, w_split=False):
+         out=None, out_rows=None, drop_p=0.0, drop_seed=0, prec=None, w_split=False, a_scale=0.0, b_scale=0.0,
+         a_scale_dev=None, b_scale_dev=None):
     """out[rowmap(m)] = act((A' @ W.T) * scale + bias + res[m % res_mod]); A [M,K], W [N,K] row-major f32 cuda."""
     lib = L.load()
     M, K = A.shape
@@ -45,7 +57,10 @@ def gemm(A, W, bias=None, scale=None, res=None, res_mod=0, relu=False, a_add=Non
     d.rowmap = rowmap.data_ptr() if rowmap is not None else None
     d.M, d.N, d.K, d.groups = M, N, K, 1
     d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)
-    d.prec, d.b_split, d.b_scale = PREC[prec], 1 if w_split else 0, float(w_split)
+    d.prec, d.b_split, d.b_scale = PREC[prec], 1 if w_split else 0, float(w_split) if w_split else float(b_scale)
+    d.a_scale = float(a_scale)
+    d.a_scale_dev = a_scale_dev.data_ptr() if a_scale_dev is not None else None
+    d.b_scale_dev = b_scale_dev.data_ptr() if b_scale_dev is not None else None
     L.check(lib.actmi_op_gemm(C.byref(d), L.current_stream_ptr()), None, "op_gemm")
     return out
 

@@ -13,6 +13,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+template <int NV>      // float4 per lane actually needed: ceil(D / 256); the loops carry no dead iterations
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                         int res_mod, const float* __restrict__ w,
                                                         const float* __restrict__ b, const float* __restrict__ w2,
@@ -24,10 +25,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int D4 = D >> 2;
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)row * D);
     const f32x4* rr = res ? reinterpret_cast<const f32x4*>(res + (int64_t)(res_mod ? row % res_mod : row) * D) : nullptr;
-    f32x4 v[MAXV];
+    f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c < D4) {
             f32x4 t = xr[c];
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     float mean = wave_sum(s) * invD;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         if (lane + 64 * i < D4) {
             const f32x4 d = v[i] - mean;
             q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
@@ -50,19 +51,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
     const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c < D4) v[i] = (v[i] - mean) * rstd * w4[c] + b4[c];
     }
     if (w2) {
         s = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i)
+        for (int i = 0; i < NV; ++i)
             if (lane + 64 * i < D4) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         mean = wave_sum(s) * invD;
         q = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             if (lane + 64 * i < D4) {
                 const f32x4 d = v[i] - mean;
                 q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
@@ -72,14 +73,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const f32x4* w24 = reinterpret_cast<const f32x4*>(w2);
         const f32x4* b24 = reinterpret_cast<const f32x4*>(b2);
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
             if (c < D4) v[i] = (v[i] - mean) * rstd * w24[c] + b24[c];
         }
     }
     f32x4* yr = reinterpret_cast<f32x4*>(y + (int64_t)row * D);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c < D4) yr[c] = v[i];
     }
@@ -91,7 +92,16 @@ int launch_layernorm(const float* x, const float* res, int res_mod, const float*
     if ((D & 3) || D > 64 * 4 * MAXV) { if (err) *err = "layernorm: D must be a multiple of 4 and <= 2048"; return -2; }
     if (M <= 0) return 0;
     prof_begin("layernorm_kernel", 0.0, 4.0 * M * D * (res && !res_mod ? 3.0 : 2.0), st);
-    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, res, res_mod, w, b, w2, b2, y, M, D, eps);
+    const int nv = (D / 4 + 63) / 64;
+#define ACTMI_LN(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, dim3((M + 3) / 4), dim3(256), 0, st, x, res, res_mod, w, b, w2, b2, y, M, D, eps)
+    switch (nv) {
+        case 1: ACTMI_LN(1); break;
+        case 2: ACTMI_LN(2); break;
+        case 3: ACTMI_LN(3); break;
+        case 4: ACTMI_LN(4); break;
+        default: ACTMI_LN(MAXV); break;
+    }
+#undef ACTMI_LN
     prof_end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (err) *err = std::string("layernorm launch: ") + hipGetErrorString(e); return -3; }

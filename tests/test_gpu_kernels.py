@@ -87,6 +87,26 @@ def test_gemm_f16x3_tiny_operands_degrade_to_an_absolute_floor():
     assert rel_err(got32, exp) < 2e-6
 
 
+@pytest.mark.parametrize("mag", [1e-7, 1e-3, 1.0, 3e4])
+def test_pow2_scale_and_scaled_operands(mag):
+    """operands far outside the fp16 range (gradients in the backward pass) keep fp32-grade accuracy when the kernel is
+    handed the device-computed power-of-two scale; the scale brings max|x| into [2^13, 2^14)"""
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 200, 160, 256
+    A, W = torch.randn(M, K, generator=g) * mag, torch.randn(N, K, generator=g) * 0.02
+    d = dev()
+    Ad, Wd = A.to(d), W.to(d)
+    sc = ops.pow2_scale(Ad)
+    s = float(sc[0])
+    assert s == 2.0 ** round(np.log2(s)) and 2.0 ** 13 <= float(A.abs().max()) * s < 2.0 ** 14 and float(sc[1]) == 0.0
+    exp = F.linear(A.double(), W.double())
+    got = ops.gemm(Ad, Wd, prec="f16x3", a_scale_dev=sc, b_scale=256.0)
+    assert rel_err(got, exp) < 2e-6
+    # column-sliced view (row stride > width), all-zero operand
+    assert float(ops.pow2_scale(Ad[:, :64])[0]) >= s
+    assert float(ops.pow2_scale(torch.zeros(4, 8, device=d))[0]) == 1.0
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_gemm_epilogue_features(prec):
     g = torch.Generator().manual_seed(3)
