@@ -43,8 +43,13 @@ enum { B_N = 0, B_T = 1, B_WGRAD = 2 };
 enum { PREC_F32 = 0, PREC_F16X3 = 1 };
 constexpr int ACTMI_PREC_DEFAULT_IS = ACTMI_PREC_F32;      // library default when neither descriptor nor environment says
 
+#ifndef ACTMI_LDS_PAD
+#define ACTMI_LDS_PAD 1
+#endif
+constexpr int LDS_PAD = ACTMI_LDS_PAD;      // plane stride = rows + LDS_PAD 16-byte units
+
 template <int BM, int BN, int PREC>
-constexpr int stage_f4() { return NPL * ((BM + (PREC ? 2 : 1)) + (BN + (PREC ? 2 : 1))); }
+constexpr int stage_f4() { return NPL * ((BM + LDS_PAD) + (BN + LDS_PAD)); }
 
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -58,9 +63,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     // LDS plane stride in 16-byte units.  PREC_F16X3 re-uses the 8-plane stage: plane 2*kg holds the hi halves of
-    // contraction group kg (8 consecutive k), plane 2*kg+1 the lo halves; stride = 2 mod 8 keeps the 8-byte staging
-    // writes of a wave (4 groups x 2 halves x 4 rows per 256-byte bank sweep) conflict-free.
-    constexpr int PSA = BM + (PREC ? 2 : 1), PSB = BN + (PREC ? 2 : 1);
+    // contraction group kg (8 consecutive k), plane 2*kg+1 the lo halves.  LDS stores bank on (addr/4) % 32 in groups of
+    // 16 consecutive lanes: with a stride of 1 mod 4 units the 8-byte staging stores of a group (2 rows x 4 groups x 2
+    // halves) fill the 128-byte window exactly once (a stride of 2 mod 8 measured 4 % slower: 2-way conflicts).
+    constexpr int PSA = BM + LDS_PAD, PSB = BN + LDS_PAD;
     constexpr int STAGE = stage_f4<BM, BN, PREC>();
     constexpr int NLA = (AMODE == A_T) ? 4 : BM / RPP;
     constexpr int NLB = (BMODE != B_N) ? 4 : BN / RPP;
