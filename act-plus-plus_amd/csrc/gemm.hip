@@ -54,6 +54,12 @@ constexpr int stage_f4() { return NPL * ((BM + LDS_PAD) + (BN + LDS_PAD)); }
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
+// Row swizzle of the transposed-staging forms.  A thread of those loaders holds 4 CONSECUTIVE out-rows of one k group, so
+// the 8/16 lanes of an LDS store group would hit rows 64 bytes apart -- 2 distinct bank slots, a 4- to 8-way conflict.
+// XOR-ing the two low row bits with bits 3-4 spreads a group over all 8 slots; the fragment reads apply the same
+// permutation (a read group covers 32 consecutive rows either way, so reads stay conflict-free).
+__device__ __forceinline__ int swz_row(int r) { return r ^ ((r >> 3) & 3); }
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC, int BSPLIT>
@@ -138,6 +144,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     const int li = lane & 31, lh = lane >> 5;
     const int wrow0 = (wave / WAVES_N) * WM;
     const int wcol0 = (wave % WAVES_N) * WN;
+    int arow[TM], bcol[TN];          // LDS row of this lane's fragment per MFMA tile (swizzled for the transposed forms)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) arow[i] = (AMODE == A_T) ? swz_row(wrow0 + i * 32 + li) : wrow0 + i * 32 + li;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bcol[j] = (BMODE != B_N) ? swz_row(wcol0 + j * 32 + li) : wcol0 + j * 32 + li;
     const int cidx = t & 7;          // N-form staging: which 16-byte chunk of the 32-wide k tile
     const int srow = t >> 3;         // N-form staging row (plus RPP*i)
 
@@ -154,7 +165,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     unsigned a_tapmask[AMODE == A_CONV ? NLA : 1];
     int a_off0[AMODE == A_CONV ? NLA : 1];
     const float conv_inv_tpr = (AMODE == A_CONV && conv_fast) ? 1.0f / (float)(p.Cin / BK) : 0.f;
-    const float conv_inv_kw = (AMODE == A_CONV) ? 1.0f / (float)p.KW : 0.f;
+    const float conv_inv_kw = (AMODE == A_CONV || AMODE == A_DGRAD) ? 1.0f / (float)p.KW : 0.f;
+    const int dg_cq = (AMODE == A_DGRAD) ? p.K / (p.KH * p.KW) : BK;
+    const bool dgrad_fast = AMODE == A_DGRAD && (dg_cq % BK) == 0 && (p.stride == 1 || p.stride == 2) &&
+                            (int64_t)p.Ho * p.Wo * dg_cq < ((int64_t)1 << 30);
+    const float dg_inv_tpr = (AMODE == A_DGRAD) ? 1.0f / (float)(dg_cq / BK > 0 ? dg_cq / BK : 1) : 0.f;
     unsigned conv_rep = 0;                      // bit r*KW set for every filter row: replicates a column mask over the rows
     if (AMODE == A_CONV && conv_fast)
         for (int r = 0; r < p.KH; ++r) conv_rep |= 1u << (r * p.KW);
@@ -209,6 +224,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     bool b_ok[NLB];
     const int b_og = t % (BN / 4), b_kg = t / (BN / 4);
     int wg_r = 0, wg_s = 0, wg_c = 0;        // B_WGRAD: this thread's (r, s, c0) of its 4 out columns
+    const float wg_inv_hw = (BMODE == B_WGRAD) ? 1.0f / (float)(p.Ho * p.Wo) : 0.f;
+    const float wg_inv_wo = (BMODE == B_WGRAD) ? 1.0f / (float)p.Wo : 0.f;
     if (BMODE == B_N) {
 #pragma unroll
         for (int i = 0; i < NLB; ++i) {
@@ -293,6 +310,23 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
                     R.ra[i] = ld4(a_ptr[i] + off);
                     R.ra_ok[i] = inb;
                 }
+            } else if (dgrad_fast) {
+                // A_DGRAD, uniform tap per K tile (Cout % 32 == 0) and stride 1 or 2: branch-free, no divisions
+                const int tpr = dg_cq / BK;
+                const int rs = (int)(((float)kt + 0.5f) * dg_inv_tpr);
+                const int nb = (kt - rs * tpr) * BK + cidx * 4;
+                const int r = (int)(((float)rs + 0.5f) * conv_inv_kw);
+                const int q = rs - r * p.KW;
+                const int sh = p.stride - 1;                 // stride 1 -> shift 0, stride 2 -> shift 1
+#pragma unroll
+                for (int i = 0; i < NLA; ++i) {
+                    const int hn = a_hi0[i] - r, wn = a_wi0[i] - q;
+                    const int ho = hn >> sh, wo = wn >> sh;
+                    const bool ok = a_ok[i] && hn >= 0 && wn >= 0 && ((hn | wn) & sh) == 0 && ho < p.Ho && wo < p.Wo;
+                    const int off = ok ? (ho * p.Wo + wo) * dg_cq + nb : 0;
+                    R.ra[i] = ld4(a_ptr[i] + off);
+                    R.ra_ok[i] = ok;
+                }
             } else {   // A_DGRAD: contraction (r, s, n) over the forward output channels
                 const int Cq = p.K / (p.KH * p.KW);
                 const int rs = k / Cq;
@@ -309,6 +343,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
                             v = ld4(a_ptr[i] + ((int64_t)ho * p.Wo + wo) * Cq + n);
                     }
                     R.ra[i] = v;
+                    R.ra_ok[i] = true;
                 }
             }
         }
@@ -347,13 +382,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
             if (b_kg < NPL) {
                 const bool ook = (n0 + b_og * 4) < p.N;
                 const int hw = p.Ho * p.Wo;
+                // pixel index -> (image, row, column) by reciprocal multiply + one-step correction instead of two integer
+                // divisions per pixel (the decode was most of this loader's instructions); the 4 pixels are consecutive
+                const int mm0 = kt * BK + b_kg * 4;
+                int pb = (int)((float)mm0 * wg_inv_hw);
+                int prem = mm0 - pb * hw;
+                if (prem < 0) { --pb; prem += hw; } else if (prem >= hw) { ++pb; prem -= hw; }
+                int pho = (int)((float)prem * wg_inv_wo);
+                int pwo = prem - pho * p.Wo;
+                if (pwo < 0) { --pho; pwo += p.Wo; } else if (pwo >= p.Wo) { ++pho; pwo -= p.Wo; }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int mm = kt * BK + b_kg * 4 + j;
+                    const int mm = mm0 + j;
                     f32x4 v = zero4;
+                    const int b = pb, ho = pho, wo = pwo;
+                    if (++pwo == p.Wo) { pwo = 0; if (++pho == p.Ho) { pho = 0; ++pb; } }
                     if (ook && mm < p.K) {
-                        const int b = mm / hw, rem = mm - b * hw;
-                        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
                         const int hi = ho * p.stride - p.pad + wg_r, wi = wo * p.stride - p.pad + wg_s;
                         if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
                             v = ld4(Bw + (int64_t)b * p.img_stride + ((int64_t)hi * p.W + wi) * p.Cin + wg_c);
@@ -387,7 +431,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
                     const f32x4 v = f32x4{R.ra[0][i], R.ra[1][i], R.ra[2][i], R.ra[3][i]} * pre_a;
                     uint2 hi, lo;
                     split16(v, hi, lo);
-                    const int row = a_og * 4 + i;
+                    const int row = swz_row(a_og * 4 + i);
                     sa8[(((a_kg >> 1) * 2 + 0) * PSA + row) * 2 + (a_kg & 1)] = hi;
                     sa8[(((a_kg >> 1) * 2 + 1) * PSA + row) * 2 + (a_kg & 1)] = lo;
                 }
@@ -397,7 +441,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
             for (int i = 0; i < NLA; ++i) {
                 f32x4 v = R.ra[i];
                 if (AMODE == A_NADD) { if (use_add) v += R.rx[i]; }
-                if (AMODE == A_CONV || (MASKED && AMODE != A_DGRAD)) v = R.ra_ok[i] ? v : zero4;
+                if (AMODE == A_CONV || AMODE == A_DGRAD || MASKED) v = R.ra_ok[i] ? v : zero4;
                 if (MASKED) v *= pre_a;
                 uint2 hi, lo;
                 split16(v, hi, lo);
@@ -428,7 +472,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
                     const f32x4 v = f32x4{R.rb[0][i], R.rb[1][i], R.rb[2][i], R.rb[3][i]} * pre_b;
                     uint2 hi, lo;
                     split16(v, hi, lo);
-                    const int row = b_og * 4 + i;
+                    const int row = swz_row(b_og * 4 + i);
                     sb8[(((b_kg >> 1) * 2 + 0) * PSB + row) * 2 + (b_kg & 1)] = hi;
                     sb8[(((b_kg >> 1) * 2 + 1) * PSB + row) * 2 + (b_kg & 1)] = lo;
                 }
@@ -443,7 +487,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const f32x4 v = {R.ra[0][i], R.ra[1][i], R.ra[2][i], R.ra[3][i]};
-                    sa[a_kg * PSA + a_og * 4 + i] = v;
+                    sa[a_kg * PSA + swz_row(a_og * 4 + i)] = v;
                 }
             }
         } else {
@@ -451,7 +495,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
             for (int i = 0; i < NLA; ++i) {
                 f32x4 v = R.ra[i];
                 if (AMODE == A_NADD) { if (use_add) v += R.rx[i]; }
-                if (AMODE != A_DGRAD) v = R.ra_ok[i] ? v : zero4;
+                v = R.ra_ok[i] ? v : zero4;
                 sa[cidx * PSA + srow + RPP * i] = v;
             }
         }
@@ -463,7 +507,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const f32x4 v = {R.rb[0][i], R.rb[1][i], R.rb[2][i], R.rb[3][i]};
-                    sb[b_kg * PSB + b_og * 4 + i] = v;
+                    sb[b_kg * PSB + swz_row(b_og * 4 + i)] = v;
                 }
             }
         }
@@ -493,13 +537,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
                 const int kg = 2 * s2 + lh;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    ah[s2][i] = sa[(kg * 2 + 0) * PSA + wrow0 + i * 32 + li];
-                    al[s2][i] = sa[(kg * 2 + 1) * PSA + wrow0 + i * 32 + li];
+                    ah[s2][i] = sa[(kg * 2 + 0) * PSA + arow[i]];
+                    al[s2][i] = sa[(kg * 2 + 1) * PSA + arow[i]];
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    bh[s2][j] = sb[(kg * 2 + 0) * PSB + wcol0 + j * 32 + li];
-                    bl[s2][j] = sb[(kg * 2 + 1) * PSB + wcol0 + j * 32 + li];
+                    bh[s2][j] = sb[(kg * 2 + 0) * PSB + bcol[j]];
+                    bl[s2][j] = sb[(kg * 2 + 1) * PSB + bcol[j]];
                 }
             }
 #pragma unroll
@@ -577,18 +621,18 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
         const f32x4* sb = sa + NPL * PSA;
         f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = sa[lh * PSA + wrow0 + i * 32 + li];
+        for (int i = 0; i < TM; ++i) af[0][i] = sa[lh * PSA + arow[i]];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = sb[lh * PSB + wcol0 + j * 32 + li];
+        for (int j = 0; j < TN; ++j) bf[0][j] = sb[lh * PSB + bcol[j]];
         constexpr bool HOT = (AMODE == A_N || AMODE == A_NADD || AMODE == A_CONV) && BMODE == B_N;
         if (PF) load_tile(kt + 1, R0);
         auto kblock = [&](auto kbc) {
             constexpr int kb = decltype(kbc)::value;
             if (kb + 1 < NPL / 2) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[(kb + 1) & 1][i] = sa[(2 * (kb + 1) + lh) * PSA + wrow0 + i * 32 + li];
+                for (int i = 0; i < TM; ++i) af[(kb + 1) & 1][i] = sa[(2 * (kb + 1) + lh) * PSA + arow[i]];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[(kb + 1) & 1][j] = sb[(2 * (kb + 1) + lh) * PSB + wcol0 + j * 32 + li];
+                for (int j = 0; j < TN; ++j) bf[(kb + 1) & 1][j] = sb[(2 * (kb + 1) + lh) * PSB + bcol[j]];
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
