@@ -18,6 +18,7 @@ constexpr int MAXV = 8;
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w;  dw += dy * xhat;  db += dy.
 // One wave per row, rows grid-strided; each wave keeps its dw/db partials in registers and adds them once.
+template <int NV>     // float4 per lane actually needed (ceil(D/256)): no dead iterations, fewer live registers
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ dy, const float* __restrict__ dx_add,
                                                      float* __restrict__ dx, float* __restrict__ dw,
@@ -27,29 +28,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     const int nw = gridDim.x * 4;
     const int D4 = D >> 2;
     const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
-    f32x4 aw[MAXV], ab[MAXV];
+    f32x4 aw[NV], ab[NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) { aw[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = aw[i]; }
+    for (int i = 0; i < NV; ++i) { aw[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = aw[i]; }
     const float invD = 1.f / (float)D;
     for (int row = wid; row < M; row += nw) {
         const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)row * D);
         const f32x4* gr = reinterpret_cast<const f32x4*>(dy + (int64_t)row * D);
-        f32x4 v[MAXV], g[MAXV];
+        f32x4 v[NV], g[NV];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
             if (c < D4) { v[i] = xr[c]; g[i] = gr[c]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
         }
         const float mean = wave_sum(s) * invD;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i)
+        for (int i = 0; i < NV; ++i)
             if (lane + 64 * i < D4) { const f32x4 d = v[i] - mean; q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]); }
         const float rstd = 1.f / sqrtf(wave_sum(q) * invD + eps);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
             if (c < D4) {
                 const f32x4 xh = (v[i] - mean) * rstd;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         f32x4* dr = reinterpret_cast<f32x4*>(dx + (int64_t)row * D);
         const f32x4* ar = dx_add ? reinterpret_cast<const f32x4*>(dx_add + (int64_t)row * D) : nullptr;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
             if (c < D4) {
                 f32x4 o = (g[i] - m1 - v[i] * m2) * rstd;
@@ -76,11 +77,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
     // block-level reduction of the 4 waves' partials through LDS, then ONE atomic per column per block
     // (4096 waves adding to the same 2*D addresses was 15x slower than the row pass itself)
-    __shared__ float s_part[2][3][64 * 4 * MAXV];
+    __shared__ float s_part[2][3][64 * 4 * NV];
     const int wv = threadIdx.x >> 6;
     if (wv > 0) {
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
             if (c < D4) {
 #pragma unroll
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     __syncthreads();
     if (wv == 0) {
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
             if (c < D4) {
 #pragma unroll
@@ -113,11 +114,15 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
                                                           int64_t total) {
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(idx % C4);
-        int64_t pix = idx / C4;
-        const int wi = (int)(pix % W); pix /= W;
-        const int hi = (int)(pix % H);
-        const int64_t img = pix / H;
+        // 32-bit index arithmetic (the host checks total < 2^31): 64-bit divisions were most of this kernel's time
+        const unsigned uidx = (unsigned)idx;
+        const unsigned upix = uidx / (unsigned)C4;
+        const int c4 = (int)(uidx - upix * (unsigned)C4);
+        const unsigned urow = upix / (unsigned)W;
+        const int wi = (int)(upix - urow * (unsigned)W);
+        const unsigned uimg = urow / (unsigned)H;
+        const int hi = (int)(urow - uimg * (unsigned)H);
+        const int64_t img = uimg;
         const f32x4* xs = reinterpret_cast<const f32x4*>(x) + img * H * W * C4 + c4;
         const f32x4* gs = reinterpret_cast<const f32x4*>(dy) + img * Ho * Wo * C4 + c4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -414,10 +419,21 @@ int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* 
                   int M, int D, float eps, hipStream_t st) {
     if ((D & 3) || D > 64 * 4 * MAXV) return -2;
     if (M <= 0) return 0;
+    // persistent workgroups (each adds its dw/db partials once): 4 per CU -- with one wave per SIMD (256 workgroups) the
+    // dependent load -> reduce -> store chain of a row ran at 0.5 TB/s
     int blocks = (M + 3) / 4;
-    if (blocks > 256) blocks = 256;
+    if (blocks > 1024) blocks = 1024;
     prof_begin("ln_bwd_kernel", 0.0, 4.0 * M * D * 3.0, st);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, x, w, dy, dx_add, dx, dw, db, M, D, eps);
+    const int nv = (D / 4 + 63) / 64;
+#define ACTMI_LNB(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(blocks), dim3(256), 0, st, x, w, dy, dx_add, dx, dw, db, M, D, eps)
+    switch (nv) {
+        case 1: ACTMI_LNB(1); break;
+        case 2: ACTMI_LNB(2); break;
+        case 3: ACTMI_LNB(3); break;
+        case 4: ACTMI_LNB(4); break;
+        default: ACTMI_LNB(MAXV); break;
+    }
+#undef ACTMI_LNB
     prof_end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -426,6 +442,7 @@ int launch_maxpool_bwd(const float* x, const float* dy, float* dx, int nimg, int
                        hipStream_t st) {
     if (C & 3) return -2;
     const int64_t total = (int64_t)nimg * H * W * (C / 4);
+    if (total >= ((int64_t)1 << 31)) return -2;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     prof_begin("maxpool_bwd_kernel", 0.0, 4.0 * nimg * C * (2.0 * H * W + (double)Ho * Wo), st);
