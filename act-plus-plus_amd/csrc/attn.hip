@@ -270,6 +270,11 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(AttnArgs p, int nsplit,
     constexpr int NLK = (KT * C4 + 255) / 256;
     constexpr int NLV = (KT / 2 * C4 + 255) / 256;
     f32x4 pk[NLK], pv[NLV][2];
+    // V item -> (key pair, 4-wide d chunk): 4 chunks x 8 key pairs per 32 lanes.  The transposed 4-byte stores of a
+    // 32-lane group then spread over 16 banks (2-way); chunk-fastest numbering put them on 4 (d rows are 272 B apart,
+    // so a chunk's 4 rows only contribute their parity to the bank).
+    auto vc = [&](int e) { return ((e >> 5) % (C4 / 4)) * 4 + (e & 3); };
+    auto vkp = [&](int e) { return ((e >> 5) / (C4 / 4)) * 8 + ((e >> 2) & 7); };
     auto fetch = [&](int kt0) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(AttnArgs p, int nsplit,
 #pragma unroll
         for (int i = 0; i < NLV; ++i) {
             const int e = t + 256 * i;
-            const int kp = e / C4, c = e - kp * C4;
+            const int kp = vkp(e), c = vc(e);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int key = kt0 + 2 * kp + u;
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(AttnArgs p, int nsplit,
         for (int i = 0; i < NLV; ++i) {
             const int e = t + 256 * i;
             if (e < KT / 2 * C4) {
-                const int kp = e / C4, c = e - kp * C4;
+                const int kp = vkp(e), c = vc(e);
                 uint2 ha, la, hb, lb;
                 split16(pv[i][0], ha, la);
                 split16(pv[i][1], hb, lb);
