@@ -91,6 +91,21 @@ def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1
     return out
 
 
+def conv3x3_c64(x, w_ohwi, scale=None, bias=None, res=None, relu=False, w_scale=256.0):
+    """direct 3x3/s1/p1 conv, 64 -> 64 channels, f16x3: x [G,B,H,W,64]; w_ohwi [G,64,3,3,64]; returns [G,B,H,W,64]."""
+    lib = L.load()
+    G, B, H, W, Cin = x.shape
+    assert Cin == 64 and tuple(w_ohwi.shape[1:]) == (64, 3, 3, 64)
+    out = torch.empty_like(x)
+    w16 = split16(w_ohwi, w_scale)
+    scale = scale if scale is not None else torch.ones(G, 64, device=x.device)
+    bias = bias if bias is not None else torch.zeros(G, 64, device=x.device)
+    L.check(lib.actmi_op_conv3x3_c64(_p(x.contiguous()), _p(w16), float(w_scale), _p(scale.contiguous()), _p(bias.contiguous()),
+                                     _p(res), _p(out), G, B, H, W, 1 if relu else 0, L.current_stream_ptr()), None,
+            "op_conv3x3_c64")
+    return out
+
+
 def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False, split=True, drop_p=0.0, drop_seed=0, prec=None):
     """q [B,Nq,D] (or [Nq,D] when q_shared), k/v [B,Nk,D] (views with row stride allowed); returns [B,Nq,D]."""
     lib = L.load()

@@ -167,6 +167,16 @@ int actmi_op_conv1(const void* image, int image_fmt, const float* w_oihw, const 
     return launch_conv1(a, S(stream), &g_op_error);
 }
 
+int actmi_op_conv3x3_c64(const float* x, const float* w16, float w_scale, const float* scale, const float* bias,
+                         const float* res, float* out, int G, int B, int H, int W, int relu, void* stream) {
+    g_op_error.clear();
+    Conv3Args a;
+    a.x = x; a.w16 = w16; a.scale = scale; a.bias = bias; a.res = res; a.out = out;
+    a.G = G; a.B = B; a.H = H; a.W = W; a.relu = relu & 1; a.w_scale = w_scale;
+    a.dbg_skip = relu >> 8;       // timing experiments: bits 8.. of `relu`
+    return launch_conv3x3_c64(a, S(stream), &g_op_error);
+}
+
 const char* actmi_op_last_error(void) { return g_op_error.c_str(); }
 
 int actmi_set_gemm_prec(actmi_handle h, int prec) {

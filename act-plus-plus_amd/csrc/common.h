@@ -35,6 +35,20 @@ struct Conv1Args {
 };
 int launch_conv1(const Conv1Args& a, hipStream_t st, std::string* err);
 
+// ---- direct 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels, f16x3 (conv3.hip) ----------
+struct Conv3Args {
+    const float* x;       // camera-major NHWC [G][B][H][W][64]
+    const float* w16;     // fp16-split image of the weights [G][64 cout][(r,s,c) = 576], built with scale w_scale
+    const float* scale;   // [G][64] folded FrozenBN
+    const float* bias;    // [G][64]
+    const float* res;     // optional residual, same shape as out
+    float* out;           // [G][B][H][W][64]
+    int G, B, H, W, relu;
+    float w_scale;
+    int dbg_skip = 0;     // timing experiments only: 1 = no patch loads, 2 = no tap loop, 4 = no epilogue, 8 = no weight fetches
+};
+int launch_conv3x3_c64(const Conv3Args& a, hipStream_t st, std::string* err);
+
 // ---- 3x3/s2/p1 max pool NHWC (pool.hip) -----------------------------------------------------
 int launch_maxpool(const float* in, float* out, int nimg, int H, int W, int C, int Ho, int Wo, hipStream_t st);
 

@@ -465,6 +465,13 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
     ctx->dbg["maxpool"] = {cur, (int64_t)C * B * ctx->H2 * ctx->W2 * w0};
     if (ctx->stop_stage == "conv1" || ctx->stop_stage == "maxpool") return 1;
     auto run_conv = [&](const ConvLayer& cl, const float* in, float* out, const float* res, int relu) -> int {
+        if (ctx->gemm_prec == ACTMI_PREC_F16X3 && cl.k == 3 && cl.stride == 1 && cl.pad == 1 && cl.cin == 64 && cl.cout == 64) {
+            // layer1: direct convolution over an LDS-resident patch (the im2col GEMM is L2-traffic bound at 64 channels)
+            Conv3Args c3;
+            c3.x = in; c3.w16 = cl.w16; c3.scale = cl.scale; c3.bias = cl.bias; c3.res = res; c3.out = out;
+            c3.G = C; c3.B = B; c3.H = cl.H; c3.W = cl.W; c3.relu = relu; c3.w_scale = W16_SCALE;
+            return launch_conv3x3_c64(c3, st, &ctx->err);
+        }
         GemmArgs a;
         memset(&a, 0, sizeof(a));
         a.mode = 1;

@@ -208,6 +208,11 @@ int actmi_op_maxpool3x3s2(const float* in_nhwc, float* out_nhwc, int nimg, int H
 int actmi_op_conv1(const void* image, int image_fmt, const float* w_oihw, const float* scale, const float* bias,
                    float* out, float* workspace /* >= C*Cout*148 + 768 floats */, int B, int C, int H, int W, int Cout,
                    int prec /* ACTMI_PREC_*, 0 = environment / native fp32 */, void* stream);
+/* direct 3x3 / stride 1 / pad 1 convolution for 64 -> 64 channels (ResNet18 layer1), f16x3: x camera-major NHWC
+ * [G][B][H][W][64]; w16 = actmi_op_split16 image (built with w_scale) of the weights [G][64][3][3][64] (cout, r, s, cin);
+ * out = act(conv * scale + bias (+ res)) */
+int actmi_op_conv3x3_c64(const float* x, const float* w16, float w_scale, const float* scale, const float* bias,
+                         const float* res, float* out, int G, int B, int H, int W, int relu, void* stream);
 const char* actmi_op_last_error(void);
 
 /* intermediate activations of the last forward (parity tests): name in {"conv1","maxpool","layer1".."layer4",

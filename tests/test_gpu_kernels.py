@@ -153,6 +153,28 @@ def test_conv_implicit_gemm(G, B, H, W, Cin, Cout, k, stride, pad, prec):
     assert rel_err(got.permute(0, 1, 4, 2, 3), exp) < 2e-6 * max(1.0, (Cin * k * k / 512) ** 0.5)
 
 
+@pytest.mark.parametrize("G,B,H,W,with_res", [(2, 2, 16, 32, True), (1, 3, 15, 20, False), (4, 1, 120, 160, True), (1, 1, 9, 70, True)])
+def test_conv3x3_c64_direct(G, B, H, W, with_res):
+    """the LDS-patch 3x3 convolution of layer1 (f16x3) against torch fp64, incl. ragged tiles (H % 8, W % 32 != 0)"""
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(G, B, 64, H, W, generator=g)
+    w = torch.randn(G, 64, 64, 3, 3, generator=g) / 24.0
+    scale, bias = torch.rand(G, 64, generator=g) + 0.5, torch.randn(G, 64, generator=g)
+    res = torch.randn(G, B, 64, H, W, generator=g) if with_res else None
+    exp = torch.stack([torch.relu(F.conv2d(x[i].double(), w[i].double(), None, 1, 1) * scale[i].double().view(1, -1, 1, 1)
+                                  + bias[i].double().view(1, -1, 1, 1) + (res[i].double() if with_res else 0.0))
+                       for i in range(G)])
+    d = dev()
+    got = ops.conv3x3_c64(x.permute(0, 1, 3, 4, 2).contiguous().to(d), w.permute(0, 1, 3, 4, 2).contiguous().to(d),
+                          scale.to(d), bias.to(d), res.permute(0, 1, 3, 4, 2).contiguous().to(d) if with_res else None, relu=True)
+    assert rel_err(got.permute(0, 1, 4, 2, 3), exp) < 2e-6
+    # same bits as the implicit-GEMM path up to summation order: compare loosely against it too
+    ref = ops.conv2d_nhwc(x.permute(0, 1, 3, 4, 2).contiguous().to(d), w.permute(0, 1, 3, 4, 2).contiguous().to(d),
+                          scale.to(d), bias.to(d), res.permute(0, 1, 3, 4, 2).contiguous().to(d) if with_res else None,
+                          relu=True, stride=1, pad=1, prec="f16x3")
+    assert rel_err(got, ref) < 2e-6
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,hd,masked,shared", [(2, 8, 1202, 1202, 64, False, False), (3, 8, 100, 1202, 64, False, True),
                                                        (4, 8, 102, 102, 64, True, False), (2, 4, 14, 14, 16, False, False),
                                                        (2, 4, 10, 12, 16, True, False), (1, 2, 33, 65, 32, True, False)])
