@@ -15,6 +15,9 @@ struct Param {
     bool is_buffer;
 };
 
+// the split weight image holds W * 2^8: the lo pieces of weights around 1e-2 stay normal fp16 numbers; |W| < 255 assumed
+static constexpr float W16_SCALE = 256.f;
+
 struct ConvLayer {
     std::string name, bn;
     int cin, cout, k, stride, pad, H, W, Ho, Wo;

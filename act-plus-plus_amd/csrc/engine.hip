@@ -151,9 +151,6 @@ int dev_alloc(actmi_ctx* ctx, float** p, int64_t nfloats) {
 
 }  // namespace
 
-// the split weight image holds W * 2^8: the lo pieces of weights around 1e-2 stay normal fp16 numbers; |W| < 255 assumed
-static constexpr float W16_SCALE = 256.f;
-
 int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
     a.prec = ctx->gemm_prec;
     if (ctx->gemm_prec == ACTMI_PREC_F16X3 && a.tb == 0) {

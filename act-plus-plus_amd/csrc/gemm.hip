@@ -699,7 +699,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
     // Fast epilogue for the forward-pass cases (bias / FrozenBN affine, optional same-shape residual, optional ReLU): the
     // feature-complete path below costs ~140 instructions per element (per-element branches, 64-bit index arithmetic) and
     // was measured at 45-75k cycles per 128x128 tile, a quarter of a K=512 main loop; this one is a few thousand.
-    const bool simple = !has_map && !has_mask && splitk <= 1 && !C2 && !(p.drop_p > 0.f) && p.res_mod == 0 &&
+    const bool simple = !has_map && splitk <= 1 && !C2 && !(p.drop_p > 0.f) && p.res_mod == 0 &&
+                        (!has_mask || (int64_t)p.M * ldmask < (int64_t)1 << 31) &&
                         (int64_t)p.M * p.ldc < (int64_t)1 << 31 && (!has_res || (int64_t)p.M * p.ldres < (int64_t)1 << 31);
     if (simple) {
         const bool relu = p.relu != 0;
@@ -709,6 +710,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
         // at ~2.7 TB/s chip-wide against ~6 TB/s for contiguous 16-byte stores.)
         const bool vec = n0 + BN <= p.N && (p.ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
                          (!has_res || ((p.ldres & 3) == 0 && ((uintptr_t)res & 15) == 0)) &&
+                         (!has_mask || ((ldmask & 3) == 0 && ((uintptr_t)mask & 15) == 0)) &&
                          (!scale || ((uintptr_t)scale & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
         if (vec) {
             constexpr int RS = WN + 8;               // row stride (floats): the two lane halves land 32 banks apart
@@ -737,6 +739,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
                     v = v * alpha * sc4 + bi4;
                     if (m < p.M) {
                         if (has_res) v += ld4(res + (uint32_t)(m * (int)p.ldres + ncol));
+                        if (has_mask) {
+                            const f32x4 mk = ld4(mask + (uint32_t)(m * (int)ldmask + ncol));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+                        }
                         if (relu) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -771,6 +778,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
                     const int m = mb + (e & 3) + 8 * (e >> 2);
                     float v = acc[i][j][e] * alpha * sc + bi;
                     if (has_res) v += rv[e];
+                    if (has_mask && nok && m < p.M) { if (!(mask[(uint32_t)(m * (int)ldmask + n)] > 0.f)) v = 0.f; }
                     v = relu ? fmaxf(v, 0.f) : v;
                     if (nok && m < p.M) C[(uint32_t)(m * (int)p.ldc + n)] = v;
                 }

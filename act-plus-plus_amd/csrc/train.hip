@@ -492,6 +492,12 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
         CHK(launch_maxpool(ctx->act1, T.pool, C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
     }
     auto run_conv = [&](const ConvLayer& cl, const float* in, float* out, const float* res, int relu) -> int {
+        if (ctx->gemm_prec == ACTMI_PREC_F16X3 && cl.k == 3 && cl.stride == 1 && cl.pad == 1 && cl.cin == 64 && cl.cout == 64) {
+            Conv3Args c3;           // layer1: direct convolution (conv3.hip), as in the inference engine
+            c3.x = in; c3.w16 = cl.w16; c3.scale = cl.scale; c3.bias = cl.bias; c3.res = res; c3.out = out;
+            c3.G = C; c3.B = B; c3.H = cl.H; c3.W = cl.W; c3.relu = relu; c3.w_scale = W16_SCALE;
+            return launch_conv3x3_c64(c3, st, &ctx->err);
+        }
         GemmArgs a = G0();
         a.mode = 1;
         a.A = in; a.H = cl.H; a.W = cl.W; a.Cin = cl.cin; a.KH = a.KW = cl.k; a.stride = cl.stride; a.pad = cl.pad;
