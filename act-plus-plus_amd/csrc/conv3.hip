@@ -8,13 +8,16 @@
 // into fp16 hi / lo pieces) and walks the 9 taps over it, so each input byte is read from global memory once per tile
 // (+ halo) and only the 16 KB weight slice of the current tap streams through LDS.
 //
-//   tile   8 output rows x 32 pixels x 64 channels; 512 threads = 8 waves, wave w owns output row w (32 px x 64 ch, two
-//          32x32 MFMA tiles sharing one A fragment); 120x160 maps = 15 x 5 tiles exactly.
-//   patch  10 x 34 pixels, per pixel 64 hi halfs | 64 lo halfs | 16 B pad (272 B: conflict-free 16-byte fragment reads).
+//   tile   4 output rows x 32 pixels x 64 channels; 256 threads = 4 waves, wave w owns output row w (32 px x 64 ch, two
+//          32x32 MFMA tiles sharing one A fragment).  73 KB of LDS -> two workgroups per CU, so one's patch staging and
+//          epilogue overlap the other's MFMAs (8-row tiles with double-buffered weights, one workgroup per CU: 8 % slower).
+//   patch  6 x 34 pixels, per pixel 64 hi halfs | 64 lo halfs | 16 B pad (272 B: conflict-free 16-byte fragment reads).
 //   taps   weights arrive pre-split and pre-scaled (the engine's split image of [cout][(r,s,c)], x 2^8): per tap a
-//          [64 cout][64 c] slice, double-buffered in LDS; slices are fetched four taps ahead into registers.
+//          [64 cout][64 c] slice in LDS (single buffer, two barriers per tap); slices are fetched four taps ahead into
+//          registers.
 //   K      per tap 4 steps of 16 channels (8 per lane half), 6 MFMAs (v_mfma_f32_32x32x16_f16: lo*hi, hi*lo, hi*hi) per
 //          step and wave: 216 MFMAs per wave and tile.
+//   out    the accumulator tile leaves through the dead patch area as 16-byte accesses (1 KB contiguous per instruction).
 #include "common.h"
 #include "split16.h"
 
@@ -22,15 +25,16 @@ namespace {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int TR = 8, TW = 32, CH = 64;
+constexpr int TR = 4, TW = 32, CH = 64;
+constexpr int NTHR = TR * 64;
 constexpr int PR = TR + 2, PW = TW + 2;
 constexpr int PIX = 272;                        // bytes per patch pixel
 constexpr int PATCH = PR * PW * PIX;            // 92480
 constexpr int WROW = 272;                       // bytes per cout row of a tap slice
 constexpr int WBUF = CH * WROW;                 // 17408
-constexpr int SMEM = PATCH + 2 * WBUF;          // 127296
+constexpr int SMEM = PATCH + WBUF;              // 72896: two workgroups per CU
 
-__global__ __launch_bounds__(512) void conv3x3_c64_f16x3_kernel(Conv3Args p, int tiles_w, int tiles_h) {
+__global__ __launch_bounds__(NTHR) void conv3x3_c64_f16x3_kernel(Conv3Args p, int tiles_w, int tiles_h) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* s_patch = smem;
     unsigned char* s_w = smem + PATCH;
@@ -49,20 +53,21 @@ __global__ __launch_bounds__(512) void conv3x3_c64_f16x3_kernel(Conv3Args p, int
     // ---- tap slice loader: 64 cout x 16 groups of 16 bytes = 1024 groups, 2 per thread.  Slices run WD taps ahead in
     //      registers (a tap is only ~770 MFMA cycles per wave, a global round trip 2-4x that), one tap ahead in LDS.
     constexpr int WD = 4;
-    uint4 wreg[WD][2];
-    auto fetch_w = [&](int tap, uint4 (&wr)[2]) {
+    constexpr int NWG = 1024 / NTHR;
+    uint4 wreg[WD][NWG];
+    auto fetch_w = [&](int tap, uint4 (&wr)[NWG]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = t + 512 * i;
+        for (int i = 0; i < NWG; ++i) {
+            const int e = t + NTHR * i;
             const int n = e >> 4, grp = e & 15;           // 4 channels per group
             wr[i] = *reinterpret_cast<const uint4*>(wsplit + ((int64_t)n * 9 + tap) * CH + grp * 4);
         }
     };
-    auto commit_w = [&](int buf, const uint4 (&wr)[2]) {
-        unsigned char* dst = s_w + buf * WBUF;
+    auto commit_w = [&](int buf, const uint4 (&wr)[NWG]) {
+        unsigned char* dst = s_w;      // single buffer
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = t + 512 * i;
+        for (int i = 0; i < NWG; ++i) {
+            const int e = t + NTHR * i;
             const int n = e >> 4, grp = e & 15;
             *reinterpret_cast<uint2*>(dst + n * WROW + grp * 8) = uint2{wr[i].x, wr[i].y};             // 4 hi halfs
             *reinterpret_cast<uint2*>(dst + n * WROW + 128 + grp * 8) = uint2{wr[i].z, wr[i].w};       // 4 lo halfs
@@ -73,11 +78,11 @@ __global__ __launch_bounds__(512) void conv3x3_c64_f16x3_kernel(Conv3Args p, int
 
     // ---- input patch: 10 x 34 pixels x 16 float4 groups, zero outside the image; split on the way in.  All of a thread's
     //      loads are issued before the first is consumed (a rolled loop serialised ~11 global round trips per tile).
-    constexpr int NP = (PR * PW * 16 + 511) / 512;
+    constexpr int NP = (PR * PW * 16 + NTHR - 1) / NTHR;
     f32x4 pv[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int e = t + 512 * i;
+        const int e = t + NTHR * i;
         const int grp = e & 15, pix = e >> 4;
         const int pr = pix / PW, pc = pix - pr * PW;
         const int hi = h0 - 1 + pr, wi = w0 - 1 + pc;
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_f16x3_kernel(Conv3Args p, int
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int e = t + 512 * i;
+        const int e = t + NTHR * i;
         if (e < PR * PW * 16) {
             const int grp = e & 15, pix = e >> 4;
             uint2 hv, lv;
@@ -108,12 +113,12 @@ __global__ __launch_bounds__(512) void conv3x3_c64_f16x3_kernel(Conv3Args p, int
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         if (p.dbg_skip & 2) break;
-        const int buf = tap & 1;
+        const int buf = 0;
         // slot tap % WD held this tap's slice (now in LDS): refill it with tap + WD
         if (tap + WD < 9 && !(p.dbg_skip & 8)) fetch_w(tap + WD, wreg[tap % WD]);
         const int r = tap / 3, s = tap - r * 3;
         const unsigned char* ap = s_patch + ((wave + r) * PW + li + s) * PIX + lh * 16;
-        const unsigned char* bp = s_w + buf * WBUF + li * WROW + lh * 16;
+        const unsigned char* bp = s_w + li * WROW + lh * 16;
         // all fragments of the tap first (24 x 16-byte LDS reads in flight), then its 24 MFMAs
         uint4 fa[4][2], fb[4][2][2];
 #pragma unroll
@@ -137,8 +142,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_f16x3_kernel(Conv3Args p, int
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, acc[nt], 0, 0, 0);
             }
         }
-        if (tap + 1 < 9) commit_w(buf ^ 1, wreg[(tap + 1) % WD]);     // the other buffer was last read one tap ago
-        __syncthreads();
+        __syncthreads();                                            // every wave is done with this tap's slice
+        if (tap + 1 < 9) { commit_w(buf, wreg[(tap + 1) % WD]); __syncthreads(); }
     }
 
     // ---- epilogue.  C layout: col = lane&31 (channel), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel of this wave's row).
@@ -199,7 +204,7 @@ int launch_conv3x3_c64(const Conv3Args& a, hipStream_t st, std::string* err) {
     }
     const double px = (double)a.G * a.B * a.H * a.W;
     prof_begin("conv3x3_c64_f16x3_kernel", 2.0 * px * CH * 9 * CH, 4.0 * (px * CH * (a.res ? 3.0 : 2.0) + (double)a.G * CH * 9 * CH), st);
-    hipLaunchKernelGGL(conv3x3_c64_f16x3_kernel, dim3((unsigned)blocks), dim3(512), SMEM, st, a, tiles_w, tiles_h);
+    hipLaunchKernelGGL(conv3x3_c64_f16x3_kernel, dim3((unsigned)blocks), dim3(NTHR), SMEM, st, a, tiles_w, tiles_h);
     prof_end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (err) *err = std::string("conv3x3_c64 launch: ") + hipGetErrorString(e); return -3; }
