@@ -172,8 +172,7 @@ int actmi_op_conv3x3_c64(const float* x, const float* w16, float w_scale, const 
     g_op_error.clear();
     Conv3Args a;
     a.x = x; a.w16 = w16; a.scale = scale; a.bias = bias; a.res = res; a.out = out;
-    a.G = G; a.B = B; a.H = H; a.W = W; a.relu = relu & 1; a.w_scale = w_scale;
-    a.dbg_skip = relu >> 8;       // timing experiments: bits 8.. of `relu`
+    a.G = G; a.B = B; a.H = H; a.W = W; a.relu = relu; a.w_scale = w_scale;
     return launch_conv3x3_c64(a, S(stream), &g_op_error);
 }
 

@@ -45,7 +45,6 @@ struct Conv3Args {
     float* out;           // [G][B][H][W][64]
     int G, B, H, W, relu;
     float w_scale;
-    int dbg_skip = 0;     // timing experiments only: 1 = no patch loads, 2 = no tap loop, 4 = no epilogue, 8 = no weight fetches
 };
 int launch_conv3x3_c64(const Conv3Args& a, hipStream_t st, std::string* err);
 

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_f16x3_kernel(Conv3Args p, in
         const int grp = e & 15, pix = e >> 4;
         const int pr = pix / PW, pc = pix - pr * PW;
         const int hi = h0 - 1 + pr, wi = w0 - 1 + pc;
-        const bool ok = !(p.dbg_skip & 1) && e < PR * PW * 16 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        const bool ok = e < PR * PW * 16 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
         const f32x4 v = *reinterpret_cast<const f32x4*>(xin + (ok ? ((int64_t)hi * p.W + wi) * CH + grp * 4 : 0));
         pv[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -112,10 +112,9 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_f16x3_kernel(Conv3Args p, in
 
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        if (p.dbg_skip & 2) break;
         const int buf = 0;
         // slot tap % WD held this tap's slice (now in LDS): refill it with tap + WD
-        if (tap + WD < 9 && !(p.dbg_skip & 8)) fetch_w(tap + WD, wreg[tap % WD]);
+        if (tap + WD < 9) fetch_w(tap + WD, wreg[tap % WD]);
         const int r = tap / 3, s = tap - r * 3;
         const unsigned char* ap = s_patch + ((wave + r) * PW + li + s) * PIX + lh * 16;
         const unsigned char* bp = s_w + li * WROW + lh * 16;
@@ -151,7 +150,6 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_f16x3_kernel(Conv3Args p, in
     //      of a 380 us launch).  The wave's 32 px x 64 ch tile goes through the now dead patch area instead and leaves as
     //      16-byte accesses: 16 lanes cover one pixel's 64 channels, an instruction 4 consecutive pixels = 1 KB contiguous.
     const int ho = h0 + wave;
-    if (p.dbg_skip & 4) return;
     constexpr int RS = CH + 4;                                    // scratch row stride in floats
     float* scr = reinterpret_cast<float*>(s_patch) + wave * (TW * RS);
 #pragma unroll
