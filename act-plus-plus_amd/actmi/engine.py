@@ -6,6 +6,7 @@ reference's state_dict.
 """
 from collections import OrderedDict
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -13,6 +14,10 @@ import torch
 from . import lib as L
 from .config import ACTConfig
 from .weights import act_state_dict_spec, is_buffer
+
+
+# ACTMI_CHECK_FINITE=1: verify every inference output (one host sync per call; off by default)
+_CHECK_FINITE = os.environ.get("ACTMI_CHECK_FINITE") == "1"
 
 
 class ACTEngine:
@@ -130,6 +135,10 @@ class ACTEngine:
             out = torch.empty((B, cfg.num_queries, cfg.action_dim), dtype=torch.float32, device=qpos.device)
         L.check(self.lib.actmi_forward_infer(self.h, C.c_void_p(qpos.data_ptr()), C.c_void_p(image.data_ptr()), fmt, B,
                                              C.c_void_p(out.data_ptr()), L.current_stream_ptr()), self.h, "forward_infer")
+        if _CHECK_FINITE and not bool(torch.isfinite(out).all()):
+            # f16x3 needs finite operands with |x| < 65504: an activation beyond that shows up here
+            raise FloatingPointError("non-finite a_hat: an operand left the fp16-split range; rerun with gemm_prec='f32' "
+                                     "(ACTMI_GEMM_PREC=f32)")
         return out
 
     def capture_infer(self, batch: int, image_dtype=torch.uint8, with_ensemble=None):
