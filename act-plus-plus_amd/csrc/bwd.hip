@@ -438,6 +438,53 @@ int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* 
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// gather form on the recorded argmax codes (maxpool_idx_kernel): an input element (hi, wi) lies in at most 2 x 2 windows;
+// it receives dy of those whose code names its position
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const uint8_t* __restrict__ arg, const float* __restrict__ dy,
+                                                              float* __restrict__ dx, int H, int W, int C4, int Ho, int Wo,
+                                                              unsigned total) {
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned pix0 = idx / (unsigned)C4;
+        const int c4 = (int)(idx - pix0 * (unsigned)C4);
+        const unsigned row = pix0 / (unsigned)W;
+        const int wi = (int)(pix0 - row * (unsigned)W);
+        const unsigned img = row / (unsigned)H;
+        const int hi = (int)(row - img * (unsigned)H);
+        const int64_t obase = (int64_t)img * Ho * Wo * C4 + c4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int ho_lo = hi >> 1, ho_hi = (hi + 1) >> 1;      // windows with 2ho-1 <= hi <= 2ho+1
+        const int wo_lo = wi >> 1, wo_hi = (wi + 1) >> 1;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            if (ho >= Ho) continue;
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                if (wo >= Wo) continue;
+                const int me = (hi - (2 * ho - 1)) * 3 + (wi - (2 * wo - 1));
+                const int64_t o = obase + ((int64_t)ho * Wo + wo) * C4;
+                const uchar4 a = reinterpret_cast<const uchar4*>(arg)[o];
+                const f32x4 g = reinterpret_cast<const f32x4*>(dy)[o];
+                if (a.x == me) acc[0] += g[0];
+                if (a.y == me) acc[1] += g[1];
+                if (a.z == me) acc[2] += g[2];
+                if (a.w == me) acc[3] += g[3];
+            }
+        }
+        reinterpret_cast<f32x4*>(dx)[idx] = acc;
+    }
+}
+
+int launch_maxpool_bwd_idx(const uint8_t* arg, const float* dy, float* dx, int nimg, int H, int W, int C, int Ho, int Wo,
+                           hipStream_t st) {
+    if (C & 3) return -2;
+    const int64_t total = (int64_t)nimg * H * W * (C / 4);
+    if (total >= ((int64_t)1 << 31)) return -2;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    prof_begin("maxpool_bwd_idx_kernel", 0.0, 4.0 * nimg * C * ((double)H * W + 1.25 * Ho * Wo), st);
+    hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3((unsigned)blocks), dim3(256), 0, st, arg, dy, dx, H, W, C / 4, Ho, Wo, (unsigned)total);
+    prof_end(st);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 int launch_maxpool_bwd(const float* x, const float* dy, float* dx, int nimg, int H, int W, int C, int Ho, int Wo,
                        hipStream_t st) {
     if (C & 3) return -2;

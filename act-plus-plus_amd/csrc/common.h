@@ -50,6 +50,9 @@ int launch_conv3x3_c64(const Conv3Args& a, hipStream_t st, std::string* err);
 
 // ---- 3x3/s2/p1 max pool NHWC (pool.hip) -----------------------------------------------------
 int launch_maxpool(const float* in, float* out, int nimg, int H, int W, int C, int Ho, int Wo, hipStream_t st);
+int launch_maxpool_idx(const float* in, float* out, uint8_t* arg, int nimg, int H, int W, int C, int Ho, int Wo, hipStream_t st);
+int launch_maxpool_bwd_idx(const uint8_t* arg, const float* dy, float* dx, int nimg, int H, int W, int C, int Ho, int Wo,
+                           hipStream_t st);
 
 // ---- LayerNorm (layernorm.hip) ----------------------------------------------------------------
 // y = LN(x + res[m % res_mod]) * w + b ; optional second LN (w2,b2) applied on top.

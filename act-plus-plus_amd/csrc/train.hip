@@ -378,6 +378,11 @@ int train_create(actmi_ctx* ctx) {
         T.conv_gw.push_back(gw); T.conv_wd.push_back(wd);
     }
     TA(T.conv1_gw, (int64_t)C * w0 * 196);
+    {
+        float* pa = nullptr;           // argmax codes of the stem max-pool, one byte per pooled element
+        TA(pa, ((int64_t)C * B * ctx->H2 * ctx->W2 * w0 + 3) / 4);
+        T.pool_arg = reinterpret_cast<uint8_t*>(pa);
+    }
     TA(T.scale_slots, 2 * SCALE_SLOTS);
     if (hipMemset(T.scale_slots, 0, 2 * SCALE_SLOTS * 4) != hipSuccess) { ctx->err = "hipMemset failed"; return ACTMI_E_LAUNCH; }
     // transformer saves
@@ -489,7 +494,7 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
         c1.Ho = ctx->H1; c1.Wo = ctx->W1; c1.Cout = w0;
         c1.prec = ctx->gemm_prec;
         CHK(launch_conv1(c1, st, &ctx->err));
-        CHK(launch_maxpool(ctx->act1, T.pool, C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
+        CHK(launch_maxpool_idx(ctx->act1, T.pool, T.pool_arg, C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
     }
     auto run_conv = [&](const ConvLayer& cl, const float* in, float* out, const float* res, int relu) -> int {
         if (ctx->gemm_prec == ACTMI_PREC_F16X3 && cl.k == 3 && cl.stride == 1 && cl.pad == 1 && cl.cin == 64 && cl.cout == 64) {
@@ -816,7 +821,7 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
         }
     }
     // stem: maxpool, relu, bn1, conv1 weight gradient through the NHWC4 normalised image
-    CHK(launch_maxpool_bwd(ctx->act1, gcur, T.g_act1, C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
+    CHK(launch_maxpool_bwd_idx(T.pool_arg, gcur, T.g_act1, C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
     CHK(launch_relu_bn_bwd(T.g_act1, nullptr, ctx->act1, ctx->conv1_scale, nullptr, T.g_act1, C,
                            (int64_t)B * ctx->H1 * ctx->W1 * w0, w0, st));
     {
