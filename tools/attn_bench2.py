@@ -19,6 +19,7 @@ for (Nq, Nk, shared, tag) in [(1202, 1202, False, "encoder self-attn"), (100, 12
     q = torch.randn((Nq, 512) if shared else (B, Nq, 512), device=dev)
     kv = torch.randn(B, Nk, 1024, device=dev)
     for prec in ("f32", "f16x3"):
-        ms = timeit(lambda: ops.attention(q, kv[..., :512], kv[..., 512:], 8, q_shared=shared, prec=prec))
-        fl = 4.0 * B * 8 * Nq * Nk * 64
-        print(f"{tag:20s} {prec:6s} {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF")
+        for split in (True, False):
+            ms = timeit(lambda: ops.attention(q, kv[..., :512], kv[..., 512:], 8, q_shared=shared, prec=prec, split=split))
+            fl = 4.0 * B * 8 * Nq * Nk * 64
+            print(f"{tag:20s} {prec:6s} split-KV={split!s:5s} {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF")
