@@ -48,6 +48,16 @@ class ACTConfig:
     base_width: int = 64
 
     @property
+    def latent_in_dim(self) -> int:
+        """in_features of latent_out_proj: the VQ code size when vq, else latent_dim (detr_vae.py:59-62)."""
+        return self.vq_class * self.vq_dim if self.vq else self.latent_dim
+
+    @property
+    def latent_proj_dim(self) -> int:
+        """out_features of latent_proj (detr_vae.py:50-53)."""
+        return self.vq_class * self.vq_dim if self.vq else 2 * self.latent_dim
+
+    @property
     def num_cams(self) -> int:
         return len(self.camera_names)
 
@@ -76,7 +86,12 @@ class ACTConfig:
         if self.backbone != "resnet18":
             raise NotImplementedError("only resnet18 is on the accelerated path (reference imitate_episodes.py:73)")
         if self.vq:
-            raise NotImplementedError("VQ-ACT is out of scope for this path (SURVEY §8 f4)")
+            # VQ-ACT (detr_vae.py:50-60): the latent is a [vq_class x vq_dim] one-hot code.  Inference with a given
+            # `vq_sample` is on the accelerated path; VQ training and the latent prior model are not.
+            if not self.vq_class or not self.vq_dim or self.vq_class <= 0 or self.vq_dim <= 0:
+                raise ValueError("vq needs positive vq_class and vq_dim")
+            if (self.vq_class * self.vq_dim) % 4:
+                raise ValueError("vq_class * vq_dim must be a multiple of 4")
         if self.pre_norm:
             raise NotImplementedError("pre_norm is never enabled by the reference CLI")
         if self.hidden_dim % self.nheads:

@@ -37,7 +37,8 @@ class ACTEngine:
                           enc_layers=cfg.enc_layers, dec_layers=cfg.dec_layers, num_queries=cfg.num_queries,
                           state_dim=cfg.state_dim, action_dim=cfg.action_dim, latent_dim=cfg.latent_dim,
                           has_cvae_encoder=0 if cfg.no_encoder else 1, max_batch=self.max_batch,
-                          enable_training=1 if training else 0, kl_weight=float(cfg.kl_weight))
+                          enable_training=1 if training else 0, kl_weight=float(cfg.kl_weight),
+                          vq=1 if cfg.vq else 0, vq_class=int(cfg.vq_class or 0), vq_dim=int(cfg.vq_dim or 0))
         h = C.c_void_p()
         rc = self.lib.actmi_create(C.byref(c), C.byref(h))
         if rc != 0:
@@ -117,7 +118,8 @@ class ACTEngine:
             raise ValueError(f"image shape {tuple(image.shape)} != {want}")
         return fmt
 
-    def forward_infer(self, qpos: torch.Tensor, image: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    def forward_infer(self, qpos: torch.Tensor, image: torch.Tensor, out: torch.Tensor = None,
+                      vq_sample: torch.Tensor = None) -> torch.Tensor:
         if not self._finalized:
             self.finalize()
         cfg = self.cfg
@@ -133,8 +135,18 @@ class ACTEngine:
             raise ValueError(f"qpos shape {tuple(qpos.shape)} != {(B, cfg.state_dim)}")
         if out is None:
             out = torch.empty((B, cfg.num_queries, cfg.action_dim), dtype=torch.float32, device=qpos.device)
-        L.check(self.lib.actmi_forward_infer(self.h, C.c_void_p(qpos.data_ptr()), C.c_void_p(image.data_ptr()), fmt, B,
-                                             C.c_void_p(out.data_ptr()), L.current_stream_ptr()), self.h, "forward_infer")
+        if cfg.vq:
+            # VQ-ACT: the latent code comes from the caller (the latent prior model's sample, imitate_episodes.py:393-394)
+            if vq_sample is None:
+                raise ValueError("a vq policy needs vq_sample [B, vq_class, vq_dim] (reference policy.py:322-332)")
+            code = vq_sample.to(device=qpos.device, dtype=torch.float32).reshape(B, cfg.vq_class * cfg.vq_dim).contiguous()
+            L.check(self.lib.actmi_forward_infer_vq(self.h, C.c_void_p(qpos.data_ptr()), C.c_void_p(image.data_ptr()), fmt,
+                                                    B, C.c_void_p(code.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                    L.current_stream_ptr()), self.h, "forward_infer_vq")
+        else:
+            L.check(self.lib.actmi_forward_infer(self.h, C.c_void_p(qpos.data_ptr()), C.c_void_p(image.data_ptr()), fmt, B,
+                                                 C.c_void_p(out.data_ptr()), L.current_stream_ptr()), self.h,
+                    "forward_infer")
         if _CHECK_FINITE and not bool(torch.isfinite(out).all()):
             # f16x3 needs finite operands with |x| < 65504: an activation beyond that shows up here
             raise FloatingPointError("non-finite a_hat: an operand left the fp16-split range; rerun with gemm_prec='f32' "

@@ -20,7 +20,7 @@ class ActmiConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "num_cams", "image_h", "image_w", "base_width", "hidden_dim", "nheads", "dim_feedforward", "enc_layers",
         "dec_layers", "num_queries", "state_dim", "action_dim", "latent_dim", "has_cvae_encoder", "max_batch",
-        "enable_training")] + [("kl_weight", C.c_float)]
+        "enable_training")] + [("kl_weight", C.c_float)] + [(n, C.c_int32) for n in ("vq", "vq_class", "vq_dim")]
 
 
 class GemmDesc(C.Structure):
@@ -83,6 +83,7 @@ def load():
         "actmi_set_param": ([vp, C.c_char_p, vp, C.POINTER(i64), i32, i32], i32),
         "actmi_get_param": ([vp, C.c_char_p, vp, i64, i32], i32),
         "actmi_finalize": ([vp, vp], i32),
+        "actmi_forward_infer_vq": ([vp, vp, vp, i32, i32, vp, vp, vp], i32),
         "actmi_forward_infer": ([vp, vp, vp, i32, i32, vp, vp], i32),
         "actmi_forward_train": ([vp, vp, vp, i32, vp, vp, vp, C.c_uint64, f32, i32, vp, vp, vp, vp, vp], i32),
         "actmi_backward": ([vp, f32, vp], i32),

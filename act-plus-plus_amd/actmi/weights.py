@@ -147,8 +147,8 @@ def act_state_dict_spec(cfg: ACTConfig, prefix: str = "") -> "OrderedDict[str, t
     o["cls_embed.weight"] = (1, D)
     o["encoder_action_proj.weight"] = (D, A); o["encoder_action_proj.bias"] = (D,)
     o["encoder_joint_proj.weight"] = (D, S); o["encoder_joint_proj.bias"] = (D,)
-    o["latent_proj.weight"] = (2 * L, D); o["latent_proj.bias"] = (2 * L,)
-    o["latent_out_proj.weight"] = (D, L); o["latent_out_proj.bias"] = (D,)
+    o["latent_proj.weight"] = (cfg.latent_proj_dim, D); o["latent_proj.bias"] = (cfg.latent_proj_dim,)
+    o["latent_out_proj.weight"] = (D, cfg.latent_in_dim); o["latent_out_proj.bias"] = (D,)
     o["additional_pos_embed.weight"] = (2, D)
     if prefix:
         o = OrderedDict((prefix + k, v) for k, v in o.items())
@@ -226,6 +226,13 @@ def generate_inputs(cfg: ACTConfig, batch: int, seed: int = 1234, with_actions: 
     img = rand_u8(seed, "image", (batch, C, cfg.image_h, cfg.image_w, 3))
     qpos = normal(seed, "qpos", batch * cfg.state_dim).astype(np.float32).reshape(batch, cfg.state_dim)
     out = {"image_u8": img, "qpos": qpos}
+    if cfg.vq:
+        # one-hot code per class, as Latent_Model_Transformer.generate emits (latent_model.py:60-72)
+        pick = (uniform01(seed, "vq_pick", batch * cfg.vq_class) * cfg.vq_dim).astype(np.int64).reshape(batch, cfg.vq_class)
+        code = np.zeros((batch, cfg.vq_class, cfg.vq_dim), dtype=np.float32)
+        for b in range(batch):
+            code[b, np.arange(cfg.vq_class), np.minimum(pick[b], cfg.vq_dim - 1)] = 1.0
+        out["vq_sample"] = code
     if with_actions:
         Q, A = cfg.num_queries, cfg.action_dim
         out["actions"] = normal(seed, "actions", batch * Q * A).astype(np.float32).reshape(batch, Q, A)

@@ -71,7 +71,15 @@ int actmi_forward_infer(actmi_handle h, const float* qpos, const void* image, in
                         void* stream) {
     if (!h) return ACTMI_E_INVALID;
     if (!qpos || !image || !a_hat) return bad(h, "null pointer");
-    return engine_forward_infer(h, qpos, image, image_fmt, B, a_hat, S(stream));
+    return engine_forward_infer(h, qpos, image, image_fmt, B, a_hat, S(stream), nullptr);
+}
+
+int actmi_forward_infer_vq(actmi_handle h, const float* qpos, const void* image, int image_fmt, int B,
+                           const float* vq_sample, float* a_hat, void* stream) {
+    if (!h) return ACTMI_E_INVALID;
+    if (!qpos || !image || !a_hat || !vq_sample) return bad(h, "null pointer");
+    if (!h->cfg.vq) return bad(h, "handle was not created with vq = 1");
+    return engine_forward_infer(h, qpos, image, image_fmt, B, a_hat, S(stream), vq_sample);
 }
 
 int actmi_forward_train(actmi_handle h, const float* qpos, const void* image, int image_fmt, const float* actions,

@@ -130,9 +130,11 @@ void build_spec(actmi_ctx* c) {
     add_param(c, "encoder_action_proj.bias", {D}, false);
     add_param(c, "encoder_joint_proj.weight", {D, S}, false);
     add_param(c, "encoder_joint_proj.bias", {D}, false);
-    add_param(c, "latent_proj.weight", {2 * L, D}, false);
-    add_param(c, "latent_proj.bias", {2 * L}, false);
-    add_param(c, "latent_out_proj.weight", {D, L}, false);
+    // VQ-ACT swaps the Gaussian latent for a [vq_class x vq_dim] code (detr_vae.py:50-60)
+    const int Lp = g.vq ? g.vq_class * g.vq_dim : 2 * L, Li = g.vq ? g.vq_class * g.vq_dim : L;
+    add_param(c, "latent_proj.weight", {Lp, D}, false);
+    add_param(c, "latent_proj.bias", {Lp}, false);
+    add_param(c, "latent_out_proj.weight", {D, Li}, false);
     add_param(c, "latent_out_proj.bias", {D}, false);
     add_param(c, "additional_pos_embed.weight", {2, D}, false);
 }
@@ -238,6 +240,11 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
     }
     const int hd = g.hidden_dim / g.nheads;
     if (hd != 16 && hd != 32 && hd != 64) { g_create_error = "head_dim must be 16, 32 or 64"; return ACTMI_E_INVALID; }
+    if (g.vq && (g.vq_class < 1 || g.vq_dim < 1 || ((g.vq_class * g.vq_dim) & 3))) {
+        g_create_error = "vq needs positive vq_class, vq_dim with vq_class*vq_dim a multiple of 4";
+        return ACTMI_E_INVALID;
+    }
+    if (g.vq && g.enable_training) { g_create_error = "VQ training is not supported (enable_training must be 0 with vq)"; return ACTMI_E_INVALID; }
     actmi_ctx* ctx = new actmi_ctx();
     ctx->cfg = g;
     ctx->ptotal = 0;
@@ -588,7 +595,7 @@ int engine_decoder_infer(actmi_ctx* ctx, int B, float* a_hat, hipStream_t st) {
 }
 
 int engine_forward_infer(actmi_ctx* ctx, const float* qpos, const void* image, int fmt, int B, float* a_hat,
-                         hipStream_t st) {
+                         hipStream_t st, const float* vq_sample) {
     ctx->err.clear();
     if (!ctx->finalized) { ctx->err = "forward before finalize"; return ACTMI_E_STATE; }
     if (B < 1 || B > ctx->cfg.max_batch) { ctx->err = "batch exceeds max_batch"; return ACTMI_E_INVALID; }
@@ -600,8 +607,16 @@ int engine_forward_infer(actmi_ctx* ctx, const float* qpos, const void* image, i
         if (rc == 1) return 0;
         if (rc != 0) return rc;
     }
-    // token 0: latent_input = latent_out_proj(0) = bias (detr_vae.py:158-159); token 1: proprio (detr_vae.py:213)
-    CHK(launch_fill_rows(ctx->X, D, (int64_t)N * D, ctx->P("latent_out_proj.bias"), 0, B, D, st));
+    // token 0: latent_input = latent_out_proj(0) = bias (detr_vae.py:158-159), or latent_out_proj(code) for VQ-ACT
+    // (detr_vae.py:155-156); token 1: proprio (detr_vae.py:213)
+    if (g.vq && vq_sample) {
+        const int K = g.vq_class * g.vq_dim;
+        GemmArgs lz = linear_args(vq_sample, K, B, K, ctx->P("latent_out_proj.weight"), D, ctx->P("latent_out_proj.bias"),
+                                  ctx->X, (int64_t)N * D);
+        CHK(ctx_gemm(ctx, lz, st));
+    } else {
+        CHK(launch_fill_rows(ctx->X, D, (int64_t)N * D, ctx->P("latent_out_proj.bias"), 0, B, D, st));
+    }
     CHK(launch_small_linear(qpos, g.state_dim, ctx->P("input_proj_robot_state.weight"),
                             ctx->P("input_proj_robot_state.bias"), ctx->X + D, (int64_t)N * D, B, D, g.state_dim, st));
     ctx->dbg["src"] = {ctx->X, (int64_t)B * N * D};

@@ -46,6 +46,10 @@ typedef struct actmi_config {
     int32_t max_batch;         /* workspace is sized for this batch at create time */
     int32_t enable_training;   /* allocate gradient / optimizer / saved-activation storage */
     float kl_weight;
+    /* VQ-ACT (detr_vae.py:50-60): latent_proj emits vq_class*vq_dim logits and latent_out_proj takes the
+     * [vq_class x vq_dim] one-hot code.  Inference with a given code is supported (actmi_forward_infer_vq); VQ
+     * training is not (enable_training must be 0). */
+    int32_t vq, vq_class, vq_dim;
 } actmi_config;
 
 /* GEMM / implicit-GEMM convolution descriptor (also the unit-test entry of the MFMA kernel):
@@ -169,6 +173,11 @@ int actmi_finalize(actmi_handle h, void* stream);
 /* ---- inference: ACTPolicy.__call__(qpos, image) -> a_hat (policy.py:322-332) ----------------------- */
 int actmi_forward_infer(actmi_handle h, const float* qpos /*[B][S]*/, const void* image, int image_fmt, int B,
                         float* a_hat /*[B][Q][A]*/, void* stream);
+
+/* VQ-ACT inference, ACTPolicy.__call__(qpos, image, vq_sample=code) (policy.py:322-332, detr_vae.py:155-156): the latent
+ * token is latent_out_proj(vq_sample[b]) instead of latent_out_proj(0).  vq_sample: [B][vq_class*vq_dim] f32 device. */
+int actmi_forward_infer_vq(actmi_handle h, const float* qpos, const void* image, int image_fmt, int B,
+                           const float* vq_sample, float* a_hat, void* stream);
 
 /* ---- training: ACTPolicy.__call__(qpos, image, actions, is_pad) -> {l1, kl, loss} (policy.py:288-320) -- */
 int actmi_forward_train(actmi_handle h, const float* qpos, const void* image, int image_fmt,

@@ -191,7 +191,7 @@ def cvae_encode(sd, cfg, qpos, actions, is_pad, eps, dropout_p=0.0, p=""):
 
 
 def detrvae_forward(sd: Dict[str, torch.Tensor], cfg, qpos, image_norm, actions=None, is_pad=None, eps=None,
-                    dropout_p=0.0, live_only=False, p="", stages: Optional[dict] = None):
+                    dropout_p=0.0, live_only=False, p="", stages: Optional[dict] = None, vq_sample=None):
     """DETRVAE.forward (reference detr_vae.py:163-254) + Transformer.forward (transformer.py:49-122).
 
     image_norm: [B,C,3,H,W] already ImageNet-normalised.  ``live_only`` skips decoder layers 1.. whose
@@ -201,7 +201,14 @@ def detrvae_forward(sd: Dict[str, torch.Tensor], cfg, qpos, image_norm, actions=
     B = qpos.shape[0]
     D, H = cfg.hidden_dim, cfg.nheads
     if actions is not None:
+        if getattr(cfg, "vq", False):
+            raise NotImplementedError("VQ training (multinomial code sampling, detr_vae.py:137-145) is not restated")
         latent_input, mu, logvar = cvae_encode(sd, cfg, qpos, actions, is_pad, eps, dropout_p, p)
+    elif getattr(cfg, "vq", False):
+        # VQ-ACT inference, detr_vae.py:155-156: the latent is the given code (from the latent prior model)
+        mu = logvar = None
+        latent_input = F.linear(vq_sample.reshape(-1, cfg.vq_class * cfg.vq_dim), sd[p + "latent_out_proj.weight"],
+                                sd[p + "latent_out_proj.bias"])
     else:
         mu = logvar = None
         z = torch.zeros(B, cfg.latent_dim)
@@ -246,7 +253,8 @@ def detrvae_forward(sd: Dict[str, torch.Tensor], cfg, qpos, image_norm, actions=
     return a_hat, is_pad_hat, mu, logvar
 
 
-def policy_call(sd, cfg, qpos, image, actions=None, is_pad=None, eps=None, dropout_p=0.0, live_only=False, p="model."):
+def policy_call(sd, cfg, qpos, image, actions=None, is_pad=None, eps=None, dropout_p=0.0, live_only=False, p="model.",
+                vq_sample=None):
     """ACTPolicy.__call__, reference policy.py:264-332.  ``image`` is the reference's contract:
     f32 [B,C,3,H,W] in [0,1].  Training returns {'l1','kl','loss'} (+ a_hat, mu, logvar for tests)."""
     image = normalize_image(image)
@@ -261,7 +269,7 @@ def policy_call(sd, cfg, qpos, image, actions=None, is_pad=None, eps=None, dropo
         out["loss"] = out["l1"] + out["kl"] * cfg.kl_weight
         out["a_hat"], out["mu"], out["logvar"] = a_hat, mu, logvar
         return out
-    a_hat, _, _, _ = detrvae_forward(sd, cfg, qpos, image, live_only=live_only, p=p)
+    a_hat, _, _, _ = detrvae_forward(sd, cfg, qpos, image, live_only=live_only, p=p, vq_sample=vq_sample)
     return a_hat
 
 

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header_layout():
     import ctypes as C
     # actmi_config: 16 int32 + 1 float
-    assert C.sizeof(L.ActmiConfig) == 17 * 4
+    assert C.sizeof(L.ActmiConfig) == 20 * 4          # 16 ints, kl_weight, vq / vq_class / vq_dim
     # descriptors: natural alignment, no packing pragmas on either side
     assert C.sizeof(L.GemmDesc) % 8 == 0 and C.sizeof(L.AttnDesc) % 8 == 0
 

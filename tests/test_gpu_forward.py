@@ -152,3 +152,24 @@ def test_hipgraph_replay_equals_eager():
         raw_e = ens_e.step(a_e).clone()
         assert torch.equal(a_g, a_e)
         assert torch.equal(raw_g, raw_e)
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_vq_inference_matches_reference_golden(prec):
+    """VQ-ACT: ACTPolicy.__call__(qpos, image, vq_sample=code) against the reference's DETRVAE(vq=True) fixture."""
+    z, cfg = load_fixture("tiny_vq")
+    sd_np, inp = regenerate(z, cfg)
+    B = int(z["batch"])
+    eng = _engine(cfg, sd_np, B, prec)
+    d = eng.device
+    qpos = torch.from_numpy(inp["qpos"]).to(d)
+    img = torch.from_numpy(inp["image_u8"]).to(d)
+    code = torch.from_numpy(inp["vq_sample"]).to(d)
+    a = eng.forward_infer(qpos, img, vq_sample=code).cpu().numpy()
+    err = np.abs(a - z["infer.a_hat"]).max()
+    print(f"tiny_vq [{prec}]: max|a_hat - ref| = {err:.3e}")
+    assert err <= ATOL
+    with pytest.raises(ValueError):
+        eng.forward_infer(qpos, img)                      # a vq policy needs its code
+    other = eng.forward_infer(qpos, img, vq_sample=code.roll(1, dims=-1)).cpu().numpy()
+    assert np.abs(other - z["infer.a_hat"]).max() > 1e-4

@@ -131,3 +131,24 @@ def test_reference_reproduces_committed_fixture():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_oracle_vq_inference_matches_reference():
+    """VQ-ACT inference (detr_vae.py:155-156, policy.py:322-332 with vq_sample): fixture made by the reference's own
+    DETRVAE(vq=True) through ACTPolicy.__call__ (tools/gen_golden.py, job tiny_vq)."""
+    z, cfg = load_fixture("tiny_vq")
+    assert cfg.vq and cfg.vq_class == 4 and cfg.vq_dim == 8
+    sd_np, inp = regenerate(z, cfg)
+    sd = torch_sd(sd_np)
+    assert tuple(sd["model.latent_out_proj.weight"].shape) == (cfg.hidden_dim, 32)
+    assert tuple(sd["model.latent_proj.weight"].shape) == (32, cfg.hidden_dim)
+    image = torch.from_numpy(W.u8_nhwc_to_f32_nchw(inp["image_u8"]))
+    code = torch.from_numpy(inp["vq_sample"])
+    assert torch.equal(code.sum(-1), torch.ones(code.shape[:2]))            # one-hot per class
+    with torch.no_grad():
+        a = R.policy_call(sd, cfg, torch.from_numpy(inp["qpos"]), image, vq_sample=code)
+    assert np.abs(a.numpy() - z["infer.a_hat"]).max() < 2e-5
+    # the code matters: another code gives another action chunk
+    with torch.no_grad():
+        b = R.policy_call(sd, cfg, torch.from_numpy(inp["qpos"]), image, vq_sample=code.roll(1, dims=-1))
+    assert np.abs(b.numpy() - z["infer.a_hat"]).max() > 1e-4

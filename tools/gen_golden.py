@@ -156,13 +156,13 @@ def build_reference_policy(ref, cfg):
         backbones.append(j)
     model = ref.dv.DETRVAE(backbones, ref.tr.build_transformer(args), ref.dv.build_encoder(args),
                            state_dim=cfg.state_dim, num_queries=cfg.num_queries, camera_names=cfg.camera_names,
-                           vq=False, vq_class=None, vq_dim=None, action_dim=cfg.action_dim,
+                           vq=cfg.vq, vq_class=cfg.vq_class, vq_dim=cfg.vq_dim, action_dim=cfg.action_dim,
                            pcl_backbone=None, depth_backbones=None)
     pol = ref.policy.ACTPolicy.__new__(ref.policy.ACTPolicy)
     nn.Module.__init__(pol)
     pol.model = model
     pol.kl_weight = cfg.kl_weight
-    pol.vq = False
+    pol.vq = cfg.vq
     pol.use_depth = False
     pol.use_pcd = False
     return pol
@@ -223,8 +223,9 @@ def make_fixture(ref, name, cfg, batch, seed_w, seed_in, train=True, store_all_g
         lambda m, i, o: keep(stages, "memory", o)))
     hooks.append(pol.model.transformer.register_forward_hook(
         lambda m, i, o: keep(stages, "hs_all", o)))
+    vq_sample = torch.from_numpy(inp["vq_sample"]) if cfg.vq else None
     with torch.no_grad():
-        a_hat = pol(qpos, image)
+        a_hat = pol(qpos, image, vq_sample=vq_sample) if cfg.vq else pol(qpos, image)
     for h in hooks:
         h.remove()
     out["infer.a_hat"] = sub(a_hat)
@@ -300,8 +301,9 @@ def cross_check_oracle(cfg, out, sd_np, inp, tol=2e-5):
     image = torch.from_numpy(W.u8_nhwc_to_f32_nchw(inp["image_u8"]))
     qpos = torch.from_numpy(inp["qpos"])
     with torch.no_grad():
-        a = R.policy_call(sd, cfg, qpos, image)
-        a_live = R.policy_call(sd, cfg, qpos, image, live_only=True)
+        vq_sample = torch.from_numpy(inp["vq_sample"]) if cfg.vq else None
+        a = R.policy_call(sd, cfg, qpos, image, vq_sample=vq_sample)
+        a_live = R.policy_call(sd, cfg, qpos, image, live_only=True, vq_sample=vq_sample)
     d = float((a - torch.from_numpy(out["infer.a_hat"])).abs().max())
     d2 = float((a_live - a).abs().max())
     print(f"  oracle vs reference: max|a_hat diff| = {d:.3e}; live_only vs as-written = {d2:.3e}")
@@ -331,6 +333,9 @@ def main():
         "full4": dict(cfg=ACTConfig(), batch=2, seed_w=0, seed_in=1234, train=True, store_all_grads=False, stage_step=8192),
         "full3": dict(cfg=ACTConfig(camera_names=["top", "left_wrist", "right_wrist"]), batch=1, seed_w=3, seed_in=99,
                       train=False, store_all_grads=False, stage_step=8192),
+        # VQ-ACT inference (detr_vae.py:155-156): latent = latent_out_proj(given one-hot code)
+        "tiny_vq": dict(cfg=tiny_config(vq=True, vq_class=4, vq_dim=8), batch=3, seed_w=9, seed_in=21, train=False,
+                        store_all_grads=False, stage_step=None),
     }
     for name, j in jobs.items():
         if args.only and name != args.only:
