@@ -76,8 +76,12 @@ def _default_stats(state_dim, action_dim=16):
 
 def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, ensemble_factory=None,
             env_factory=None, stats=None, max_parallel=None, warmup_queries=0, realtime=False, verbose=True,
-            trace=None):
-    """reference imitate_episodes.py:228-526, batched + sharded.  Returns (success_rate, avg_return)."""
+            trace=None, vq_sampler=None):
+    """reference imitate_episodes.py:228-526, batched + sharded.  Returns (success_rate, avg_return).
+
+    VQ-ACT: the reference samples the latent code from its prior model each query
+    (``latent_model.generate(1, temperature=1)``, imitate_episodes.py:252-262,393-394).  That model is outside this
+    path; a caller with a prior passes ``vq_sampler(n) -> [n, vq_class, vq_dim]`` one-hot codes."""
     set_seed(1000)
     ckpt_dir = config["ckpt_dir"]
     state_dim = config["state_dim"]
@@ -112,6 +116,9 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
     pre_process = lambda s_qpos: (s_qpos - stats["qpos_mean"]) / stats["qpos_std"]          # noqa: E731
     post_process = lambda a: a * stats["action_std"] + stats["action_mean"]                  # noqa: E731
 
+    use_vq = bool(policy_config.get("vq", False))
+    if use_vq and vq_sampler is None:
+        raise NotImplementedError("VQ-ACT evaluation needs vq_sampler (the latent prior model is outside the accelerated path)")
     num_queries = policy_config["num_queries"]
     query_frequency = 1 if temporal_agg else num_queries
     action_dim = policy_config.get("action_dim", 16)
@@ -153,9 +160,10 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
                 curr_image = pinned.to(dev, non_blocking=True)
                 if t == 0:
                     for _ in range(warmup_queries):
-                        policy(qpos, curr_image)
+                        policy(qpos, curr_image, vq_sample=vq_sampler(qpos.shape[0])) if use_vq else policy(qpos, curr_image)
                 tq = time.time()
-                all_actions = policy(qpos, curr_image)                       # [E,Q,A]
+                all_actions = (policy(qpos, curr_image, vq_sample=vq_sampler(qpos.shape[0])) if use_vq
+                               else policy(qpos, curr_image))                # [E,Q,A]
                 n_queries += E
             if temporal_agg:
                 raw_action = ens.step(all_actions)                           # [E,A] float64, like the reference
