@@ -196,23 +196,30 @@ class ACTEngine:
         return replay
 
     # ---- training -----------------------------------------------------------------------------
-    def forward_train(self, qpos, image, actions, is_pad, eps=None, dropout_p: float = 0.0, dropout_seed: int = 0):
+    def forward_train(self, qpos, image, actions, is_pad, eps=None, dropout_p: float = 0.0, dropout_seed: int = 0,
+                      vq_code=None):
         """ACTPolicy.__call__ training branch (policy.py:288-320). Returns dict(l1, kl, loss, a_hat, mu, logvar) of
-        device tensors.  ``eps`` replaces the normal_() draw of reparametrize (detr_vae.py:19-22)."""
+        device tensors.  ``eps`` replaces the normal_() draw of reparametrize (detr_vae.py:19-22).
+        VQ-ACT (cfg.vq): ``vq_code`` [B, vq_class, vq_dim] replaces the multinomial draw of detr_vae.py:140 (None: drawn
+        on the device from ``dropout_seed``); the dict then carries probs, binaries and vq_discrepancy instead of
+        mu / logvar, and kl = 0 (policy.py:307-312)."""
         if not self._finalized:
             self.finalize()
         cfg = self.cfg
         B = qpos.shape[0]
-        Q, A, Lz = cfg.num_queries, cfg.action_dim, cfg.latent_dim
+        Q, A, Lz = cfg.num_queries, cfg.action_dim, cfg.latent_in_dim
         qpos = qpos.to(torch.float32).contiguous()
         image = image.contiguous()
         fmt = self._image_fmt(image, B)
         actions = actions[:, :Q].to(torch.float32).contiguous()          # policy.py:289-290
         is_pad_u8 = is_pad[:, :Q].to(torch.uint8).contiguous()
-        if eps is None:
-            eps = torch.randn((B, Lz), dtype=torch.float32, device=qpos.device)
-        eps = eps.to(torch.float32).contiguous()
         dev = qpos.device
+        if cfg.vq:
+            eps = None if vq_code is None else vq_code.to(device=dev, dtype=torch.float32).reshape(B, Lz).contiguous()
+        else:
+            if eps is None:
+                eps = torch.randn((B, Lz), dtype=torch.float32, device=dev)
+            eps = eps.to(torch.float32).contiguous()
         losses = torch.empty(3, dtype=torch.float32, device=dev)
         a_hat = torch.empty((B, Q, A), dtype=torch.float32, device=dev)
         mu = torch.empty((B, Lz), dtype=torch.float32, device=dev)
@@ -220,10 +227,17 @@ class ACTEngine:
         self._keep = (qpos, image, actions, is_pad_u8, eps)               # the library reads qpos again in backward
         L.check(self.lib.actmi_forward_train(
             self.h, C.c_void_p(qpos.data_ptr()), C.c_void_p(image.data_ptr()), fmt, C.c_void_p(actions.data_ptr()),
-            C.c_void_p(is_pad_u8.data_ptr()), C.c_void_p(eps.data_ptr()), C.c_uint64(dropout_seed), float(dropout_p), B,
-            C.c_void_p(losses.data_ptr()), C.c_void_p(a_hat.data_ptr()), C.c_void_p(mu.data_ptr()),
+            C.c_void_p(is_pad_u8.data_ptr()), C.c_void_p(eps.data_ptr() if eps is not None else 0), C.c_uint64(dropout_seed),
+            float(dropout_p), B, C.c_void_p(losses.data_ptr()), C.c_void_p(a_hat.data_ptr()), C.c_void_p(mu.data_ptr()),
             C.c_void_p(logvar.data_ptr()), L.current_stream_ptr()), self.h, "forward_train")
-        return {"l1": losses[0], "kl": losses[1], "loss": losses[2], "a_hat": a_hat, "mu": mu, "logvar": logvar}
+        out = {"l1": losses[0], "kl": losses[1], "loss": losses[2], "a_hat": a_hat}
+        if cfg.vq:
+            probs, binaries = mu.view(B, cfg.vq_class, cfg.vq_dim), logvar.view(B, cfg.vq_class, cfg.vq_dim)
+            out.update(probs=probs, binaries=binaries, mu=None, logvar=None,
+                       vq_discrepancy=(probs - binaries).abs().mean())      # F.l1_loss(probs, binaries), policy.py:311-312
+        else:
+            out.update(mu=mu, logvar=logvar)
+        return out
 
     def backward(self, loss_scale: float = 1.0):
         L.check(self.lib.actmi_backward(self.h, float(loss_scale), L.current_stream_ptr()), self.h, "backward")

@@ -573,6 +573,57 @@ int launch_reparam(const float* latent_info, const float* eps, float* z, float* 
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// ---- VQ-ACT latent (detr_vae.py:137-145): per (sample, class) a softmax over vq_dim logits and a one-hot code.  The code is
+// either given (parity tests: the reference's multinomial draw) or drawn here by inverse CDF from the counter-based
+// generator; the straight-through estimator makes latent_input = latent_out_proj(code) in the forward pass and routes
+// d(code) to the probabilities in the backward pass.
+__global__ void vq_code_kernel(const float* __restrict__ logits, const float* __restrict__ code_in, uint64_t seed,
+                               float* __restrict__ probs, float* __restrict__ code, int n, int VD) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (sample, class)
+    if (i >= n) return;
+    const float* lg = logits + (int64_t)i * VD;
+    float m = -INFINITY;
+    for (int j = 0; j < VD; ++j) m = fmaxf(m, lg[j]);
+    float s = 0.f;
+    for (int j = 0; j < VD; ++j) s += expf(lg[j] - m);
+    const float inv = 1.f / s;
+    int pick = VD - 1;
+    const float u = code_in ? 0.f : actmi_u01(seed, (uint64_t)i);
+    float cum = 0.f;
+    bool found = false;
+    for (int j = 0; j < VD; ++j) {
+        const float pj = expf(lg[j] - m) * inv;
+        probs[(int64_t)i * VD + j] = pj;
+        cum += pj;
+        if (!found && cum > u) { pick = j; found = true; }
+    }
+    for (int j = 0; j < VD; ++j)
+        code[(int64_t)i * VD + j] = code_in ? code_in[(int64_t)i * VD + j] : (j == pick ? 1.f : 0.f);
+}
+
+// softmax backward per (sample, class): dlogit_j = p_j (g_j - sum_k p_k g_k), g = d(code) through the straight-through path
+__global__ void vq_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ g, float* __restrict__ dlogits, int n,
+                              int VD) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float dot = 0.f;
+    for (int j = 0; j < VD; ++j) dot += probs[(int64_t)i * VD + j] * g[(int64_t)i * VD + j];
+    for (int j = 0; j < VD; ++j) dlogits[(int64_t)i * VD + j] = probs[(int64_t)i * VD + j] * (g[(int64_t)i * VD + j] - dot);
+}
+
+int launch_vq_code(const float* logits, const float* code_in, uint64_t seed, float* probs, float* code, int B, int VC, int VD,
+                   hipStream_t st) {
+    const int n = B * VC;
+    hipLaunchKernelGGL(vq_code_kernel, dim3((n + 255) / 256), dim3(256), 0, st, logits, code_in, seed, probs, code, n, VD);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_vq_bwd(const float* probs, const float* g, float* dlogits, int B, int VC, int VD, hipStream_t st) {
+    const int n = B * VC;
+    hipLaunchKernelGGL(vq_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, probs, g, dlogits, n, VD);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 int launch_reparam_kl_bwd(const float* latent_info, const float* eps, const float* dz, float* d_latent_info, int B, int L,
                           float klw_scaled, hipStream_t st) {
     hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3((B * L + 255) / 256), dim3(256), 0, st, latent_info, eps, dz, d_latent_info,

@@ -62,6 +62,8 @@ struct TrainState {
     // general decoder self-attention path (dropout > 0)
     float drop_p = 0.f;
     uint64_t drop_seed = 0;
+    float* vq_probs = nullptr;         // VQ-ACT: softmax of the latent logits [B][vq_class*vq_dim]
+    bool have_eps = true;              // false: no eps / code was supplied (VQ: draw the code on the device)
     uint8_t* pool_arg = nullptr;       // stem max-pool argmax codes (maxpool_idx_kernel)
     bool grads_dirty = false;
     float* scale_slots = nullptr;      // [SCALE_SLOTS][2]: device-computed operand scales of the f16x3 backward GEMMs

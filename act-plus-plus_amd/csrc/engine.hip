@@ -244,7 +244,6 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
         g_create_error = "vq needs positive vq_class, vq_dim with vq_class*vq_dim a multiple of 4";
         return ACTMI_E_INVALID;
     }
-    if (g.vq && g.enable_training) { g_create_error = "VQ training is not supported (enable_training must be 0 with vq)"; return ACTMI_E_INVALID; }
     actmi_ctx* ctx = new actmi_ctx();
     ctx->cfg = g;
     ctx->ptotal = 0;

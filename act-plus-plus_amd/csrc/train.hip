@@ -405,8 +405,10 @@ int train_create(actmi_ctx* ctx) {
         TA(T.cv_out, (int64_t)B * (Q + 2) * D);
         float* t1; TA(t1, (int64_t)B * Q); T.cmap = reinterpret_cast<int*>(t1);
         float* t2; TA(t2, ((int64_t)B * (Q + 2) + 3) / 4 + 1); T.ckpm = reinterpret_cast<uint8_t*>(t2);
-        TA(T.latent_info, (int64_t)B * 2 * L); TA(T.z, (int64_t)B * L); TA(T.eps, (int64_t)B * L);
-        TA(T.d_latent_info, (int64_t)B * 2 * L); TA(T.dz, (int64_t)B * L);
+        const int Lp = g.vq ? g.vq_class * g.vq_dim : 2 * L, Lz = g.vq ? g.vq_class * g.vq_dim : L;
+        TA(T.latent_info, (int64_t)B * Lp); TA(T.z, (int64_t)B * Lz); TA(T.eps, (int64_t)B * Lz);
+        TA(T.d_latent_info, (int64_t)B * Lp); TA(T.dz, (int64_t)B * Lz);
+        if (g.vq) TA(T.vq_probs, (int64_t)B * Lp);
     }
     // decoder layer 0 saves
     const int64_t BQ = (int64_t)B * Q;
@@ -461,8 +463,10 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
 
     // ---- CVAE encoder (detr_vae.py:117-151)
     if (g.has_cvae_encoder) {
-        if (!eps) { ctx->err = "eps is required (the reference draws it in reparametrize, detr_vae.py:19-22)"; return ACTMI_E_INVALID; }
-        HIPCHK(hipMemcpyAsync(T.eps, eps, (size_t)B * L * 4, hipMemcpyDeviceToDevice, st));
+        const int Lp = g.vq ? g.vq_class * g.vq_dim : 2 * L, Lz = g.vq ? g.vq_class * g.vq_dim : L;
+        if (!eps && !g.vq) { ctx->err = "eps is required (the reference draws it in reparametrize, detr_vae.py:19-22)"; return ACTMI_E_INVALID; }
+        T.have_eps = eps != nullptr;          // VQ: eps carries the one-hot code; NULL = draw it on the device
+        if (eps) HIPCHK(hipMemcpyAsync(T.eps, eps, (size_t)B * Lz * 4, hipMemcpyDeviceToDevice, st));
         CHK(launch_cvae_maps(T.cmap, T.ckpm, T.is_pad, B, Q, st));
         const int n = Q + 2;
         CHK(launch_fill_rows(T.Xc, D, (int64_t)n * D, ctx->P("cls_embed.weight"), 0, B, D, st));
@@ -476,11 +480,20 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
             float* out = (l + 1 < g.enc_layers) ? T.cv[l + 1].x_in : T.cv_out;
             CHK(enc_fwd(ctx, ctx->cvae[l], T.cv[l], out, ctx->P("pos_table"), B, n, T.ckpm, Drop{dropout_p, dropout_seed, (uint32_t)(8 * l)}, st));
         }
-        CHK(lin_fwd(ctx, T.cv_out, (int64_t)n * D, B, D, ctx->P("latent_proj.weight"), 2 * L, ctx->P("latent_proj.bias"),
-                    T.latent_info, 2 * L, nullptr, 0, st));
-        CHK(launch_reparam(T.latent_info, T.eps, T.z, mu_out, logvar_out, B, L, st));
-        CHK(launch_small_linear(T.z, L, ctx->P("latent_out_proj.weight"), ctx->P("latent_out_proj.bias"), ctx->X,
-                                (int64_t)N * D, B, D, L, st));
+        CHK(lin_fwd(ctx, T.cv_out, (int64_t)n * D, B, D, ctx->P("latent_proj.weight"), Lp, ctx->P("latent_proj.bias"),
+                    T.latent_info, Lp, nullptr, 0, st));
+        if (g.vq) {
+            // VQ-ACT (detr_vae.py:137-145): probs = softmax per class; code = given one-hot sample or a device draw;
+            // straight-through: latent_input = latent_out_proj(code).  mu_out / logvar_out carry probs / code.
+            CHK(launch_vq_code(T.latent_info, T.have_eps ? T.eps : nullptr, actmi_site_seed(dropout_seed, 900), T.vq_probs, T.z, B,
+                               g.vq_class, g.vq_dim, st));
+            if (mu_out) HIPCHK(hipMemcpyAsync(mu_out, T.vq_probs, (size_t)B * Lp * 4, hipMemcpyDeviceToDevice, st));
+            if (logvar_out) HIPCHK(hipMemcpyAsync(logvar_out, T.z, (size_t)B * Lz * 4, hipMemcpyDeviceToDevice, st));
+        } else {
+            CHK(launch_reparam(T.latent_info, T.eps, T.z, mu_out, logvar_out, B, L, st));
+        }
+        CHK(launch_small_linear(T.z, Lz, ctx->P("latent_out_proj.weight"), ctx->P("latent_out_proj.bias"), ctx->X,
+                                (int64_t)N * D, B, D, Lz, st));
     } else {
         CHK(launch_fill_rows(ctx->X, D, (int64_t)N * D, ctx->P("latent_out_proj.bias"), 0, B, D, st));
     }
@@ -610,7 +623,7 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
                          nullptr, nullptr, T.hs, M, D, 1e-5f, st, &ctx->err));
     CHK(lin_fwd(ctx, T.hs, D, M, D, ctx->P("action_head.weight"), A, ctx->P("action_head.bias"), T.a_hat, A, nullptr, 0, st));
     if (a_hat_out) HIPCHK(hipMemcpyAsync(a_hat_out, T.a_hat, (size_t)M * A * 4, hipMemcpyDeviceToDevice, st));
-    CHK(launch_losses(T.a_hat, T.actions, T.is_pad, g.has_cvae_encoder ? T.latent_info : nullptr, T.losses, B, Q, A, L,
+    CHK(launch_losses(T.a_hat, T.actions, T.is_pad, (g.has_cvae_encoder && !g.vq) ? T.latent_info : nullptr, T.losses, B, Q, A, L,
                       g.kl_weight, st));
     if (losses) HIPCHK(hipMemcpyAsync(losses, T.losses, 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
     T.have_forward = true;
@@ -774,8 +787,9 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
     CHK(launch_colsum(dX + D, (int64_t)N * D, GP("input_proj_robot_state.bias"), B, D, st));
     // token 0: latent_input = W_lo z + b_lo
     if (g.has_cvae_encoder) {
-        CHK(launch_small_linear_wgrad(dX, (int64_t)N * D, T.z, L, GP("latent_out_proj.weight"), B, D, L, st));
-        CHK(lin_dgrad(ctx, dX, (int64_t)N * D, B, D, ctx->P("latent_out_proj.weight"), L, T.dz, L, nullptr, nullptr, st));
+        const int Lz = g.vq ? g.vq_class * g.vq_dim : L;
+        CHK(launch_small_linear_wgrad(dX, (int64_t)N * D, T.z, Lz, GP("latent_out_proj.weight"), B, D, Lz, st));
+        CHK(lin_dgrad(ctx, dX, (int64_t)N * D, B, D, ctx->P("latent_out_proj.weight"), Lz, T.dz, Lz, nullptr, nullptr, st));
     }
     CHK(launch_colsum(dX, (int64_t)N * D, GP("latent_out_proj.bias"), B, D, st));
     // tokens 2..: input_proj (1x1 conv) of the layer4 maps
@@ -851,11 +865,13 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
     if (g.has_cvae_encoder) {
         const int n = Q + 2;
         // d latent_info from the reparametrisation and the KL term
-        CHK(launch_reparam_kl_bwd(T.latent_info, T.eps, T.dz, T.d_latent_info, B, L, g.kl_weight * loss_scale, st));
+        const int Lp = g.vq ? g.vq_class * g.vq_dim : 2 * L;
+        if (g.vq) CHK(launch_vq_bwd(T.vq_probs, T.dz, T.d_latent_info, B, g.vq_class, g.vq_dim, st));   // straight-through -> softmax
+        else CHK(launch_reparam_kl_bwd(T.latent_info, T.eps, T.dz, T.d_latent_info, B, L, g.kl_weight * loss_scale, st));
         float* dcv = T.gB;                   // grad wrt the CVAE encoder output [B][n][D]: only the CLS rows are non-zero
         HIPCHK(hipMemsetAsync(dcv, 0, (size_t)B * n * D * 4, st));
-        CHK(lin_dgrad(ctx, T.d_latent_info, 2 * L, B, 2 * L, ctx->P("latent_proj.weight"), D, dcv, (int64_t)n * D, nullptr, nullptr, st));
-        CHK(lin_wgrad(ctx, T.d_latent_info, 2 * L, B, 2 * L, T.cv_out, (int64_t)n * D, D, nullptr, 0, GP("latent_proj.weight"),
+        CHK(lin_dgrad(ctx, T.d_latent_info, Lp, B, Lp, ctx->P("latent_proj.weight"), D, dcv, (int64_t)n * D, nullptr, nullptr, st));
+        CHK(lin_wgrad(ctx, T.d_latent_info, Lp, B, Lp, T.cv_out, (int64_t)n * D, D, nullptr, 0, GP("latent_proj.weight"),
                       GP("latent_proj.bias"), st));
         for (int l = g.enc_layers - 1; l >= 0; --l)
             CHK(enc_bwd(ctx, ctx->cvae[l], T.cv[l], T.gB, T.gB, ctx->P("pos_table"), B, n, T.ckpm, nullptr,

@@ -71,15 +71,12 @@ class ACTPolicy:
         self.kl_weight = args_override["kl_weight"]
         self.vq = args_override.get("vq", False)
         mb = max_batch or int(args_override.get("max_batch", 8))
-        # VQ-ACT: inference with a given code is accelerated; VQ training / vq_encode are not
-        self.model = ACTEngine(self.cfg, max_batch=mb, device=device,
-                               training=bool(args_override.get("training", not self.vq)))
+        self.model = ACTEngine(self.cfg, max_batch=mb, device=device, training=bool(args_override.get("training", True)))
         # random init of the reference architecture (the ImageNet fetch of backbone.py:121-124 cannot run offline)
         from actmi.weights import generate_state_dict
         self.model.load_state_dict(generate_state_dict(self.cfg, seed=init_seed))
         self.training = True
-        self.optimizer = None if self.vq else _AdamW(self.model, args_override["lr"], args_override.get("lr_backbone", 1e-5),
-                                                     self.cfg.weight_decay)
+        self.optimizer = _AdamW(self.model, args_override["lr"], args_override.get("lr_backbone", 1e-5), self.cfg.weight_decay)
         self.train_dropout = float(args_override.get("train_dropout", self.cfg.dropout))
         self.dropout_seed = int(args_override.get("seed", 0))
         print(f"KL Weight {self.kl_weight}")
@@ -87,16 +84,19 @@ class ACTPolicy:
 
     def __call__(self, qpos, image, actions=None, is_pad=None, vq_sample=None, depth_img=None, pointcloud=None):
         if actions is not None:                                # training / validation (policy.py:288-320)
-            if self.vq:
-                raise NotImplementedError("VQ-ACT training is outside the accelerated path (SURVEY §8 f4)")
             eps = getattr(self, "next_eps", None)
             self.next_eps = None
             # train mode: dropout as in the reference (detr/main.py:45, 0.1); eval/validation: off (nn.Module.eval())
             p = self.train_dropout if self.training else 0.0
             self._drop_step = getattr(self, "_drop_step", 0) + 1
+            code = getattr(self, "next_vq_code", None)          # tests: replay the reference's multinomial draw
+            self.next_vq_code = None
             out = self.model.forward_train(qpos, image, actions, is_pad, eps=eps, dropout_p=p,
-                                           dropout_seed=(self.dropout_seed << 20) + self._drop_step)
-            return {"l1": out["l1"], "kl": out["kl"], "loss": _Loss.wrap(out["loss"], self)}
+                                           dropout_seed=(self.dropout_seed << 20) + self._drop_step, vq_code=code)
+            loss_dict = {"l1": out["l1"], "kl": out["kl"], "loss": _Loss.wrap(out["loss"], self)}
+            if self.vq:                                         # policy.py:311-312 (logged, not part of the loss)
+                loss_dict["vq_discrepancy"] = out["vq_discrepancy"]
+            return loss_dict
         # inference: ImageNet normalisation (policy.py:268-272) is fused into the conv1 loader
         return self.model.forward_infer(qpos, image, vq_sample=vq_sample)
 
@@ -129,4 +129,6 @@ class ACTPolicy:
 
     @torch.no_grad()
     def vq_encode(self, qpos, actions, is_pad):
-        raise NotImplementedError("VQ-ACT is outside the accelerated path (SURVEY §8 f4)")
+        """reference policy.py:336-341 (the codes the latent prior is trained on): needs the CVAE encoder alone, which
+        this library only runs as part of a full training forward."""
+        raise NotImplementedError("vq_encode / the latent prior model are outside the accelerated path (SURVEY §8 f4)")

@@ -47,8 +47,9 @@ typedef struct actmi_config {
     int32_t enable_training;   /* allocate gradient / optimizer / saved-activation storage */
     float kl_weight;
     /* VQ-ACT (detr_vae.py:50-60): latent_proj emits vq_class*vq_dim logits and latent_out_proj takes the
-     * [vq_class x vq_dim] one-hot code.  Inference with a given code is supported (actmi_forward_infer_vq); VQ
-     * training is not (enable_training must be 0). */
+     * [vq_class x vq_dim] one-hot code (actmi_forward_infer_vq; in training `eps` carries the sampled code or is NULL to
+     * draw it on the device, `mu` / `logvar` return probs / code, kl = 0 and the straight-through estimator of
+     * detr_vae.py:137-145 routes the code's gradient to the softmax). */
     int32_t vq, vq_class, vq_dim;
 } actmi_config;
 

@@ -171,7 +171,7 @@ def decoder_layer(tgt, memory, pos, query_pos, sd, p, nheads, dropout_p=0.0):
 # detr_vae.py
 # ------------------------------------------------------------------------------------------------
 
-def cvae_encode(sd, cfg, qpos, actions, is_pad, eps, dropout_p=0.0, p=""):
+def cvae_encode(sd, cfg, qpos, actions, is_pad, eps, dropout_p=0.0, p="", return_latent_info=False):
     """DETRVAE.encode, training branch, reference detr_vae.py:117-151.  ``eps`` replaces the
     ``normal_()`` draw of ``reparametrize`` (detr_vae.py:19-22) so that results are reproducible."""
     B = qpos.shape[0]
@@ -184,6 +184,8 @@ def cvae_encode(sd, cfg, qpos, actions, is_pad, eps, dropout_p=0.0, p=""):
     for i in range(cfg.enc_layers):
         x = encoder_layer(x, pos, sd, f"{p}encoder.layers.{i}.", cfg.nheads, mask, dropout_p)
     latent_info = F.linear(x[0], sd[p + "latent_proj.weight"], sd[p + "latent_proj.bias"])
+    if return_latent_info:
+        return latent_info
     mu, logvar = latent_info[:, :cfg.latent_dim], latent_info[:, cfg.latent_dim:]
     z = mu + logvar.div(2).exp() * eps
     latent_input = F.linear(z, sd[p + "latent_out_proj.weight"], sd[p + "latent_out_proj.bias"])
@@ -200,9 +202,17 @@ def detrvae_forward(sd: Dict[str, torch.Tensor], cfg, qpos, image_norm, actions=
     """
     B = qpos.shape[0]
     D, H = cfg.hidden_dim, cfg.nheads
-    if actions is not None:
-        if getattr(cfg, "vq", False):
-            raise NotImplementedError("VQ training (multinomial code sampling, detr_vae.py:137-145) is not restated")
+    if actions is not None and getattr(cfg, "vq", False):
+        # VQ training, detr_vae.py:137-145.  `vq_sample` = the one-hot code the reference draws with torch.multinomial
+        # (an explicit input here, like eps); straight-through estimator: value = code, gradient -> probs.
+        logits = cvae_encode(sd, cfg, qpos, actions, is_pad, None, dropout_p, p, return_latent_info=True)
+        probs = torch.softmax(logits.reshape(B, cfg.vq_class, cfg.vq_dim), dim=-1)
+        binaries_flat = vq_sample.reshape(B, cfg.vq_class * cfg.vq_dim)
+        probs_flat = probs.reshape(B, cfg.vq_class * cfg.vq_dim)
+        straight_through = binaries_flat - probs_flat.detach() + probs_flat
+        latent_input = F.linear(straight_through, sd[p + "latent_out_proj.weight"], sd[p + "latent_out_proj.bias"])
+        mu, logvar = probs, vq_sample.reshape(B, cfg.vq_class, cfg.vq_dim)        # returned in the (mu, logvar) slots
+    elif actions is not None:
         latent_input, mu, logvar = cvae_encode(sd, cfg, qpos, actions, is_pad, eps, dropout_p, p)
     elif getattr(cfg, "vq", False):
         # VQ-ACT inference, detr_vae.py:155-156: the latent is the given code (from the latent prior model)
@@ -261,11 +271,15 @@ def policy_call(sd, cfg, qpos, image, actions=None, is_pad=None, eps=None, dropo
     if actions is not None:
         Q = cfg.num_queries
         actions, is_pad = actions[:, :Q], is_pad[:, :Q]
-        a_hat, _, mu, logvar = detrvae_forward(sd, cfg, qpos, image, actions, is_pad, eps, dropout_p, live_only, p)
-        total_kld, _, _ = kl_divergence(mu, logvar)
+        a_hat, _, mu, logvar = detrvae_forward(sd, cfg, qpos, image, actions, is_pad, eps, dropout_p, live_only, p,
+                                               vq_sample=vq_sample)
         all_l1 = F.l1_loss(actions, a_hat, reduction="none")
         l1 = (all_l1 * ~is_pad.unsqueeze(-1)).mean()
-        out = {"l1": l1, "kl": total_kld[0]}
+        if getattr(cfg, "vq", False):                      # policy.py:307-312: no KL; the discrepancy is only logged
+            out = {"l1": l1, "kl": torch.tensor(0.0), "vq_discrepancy": F.l1_loss(mu, logvar, reduction="mean")}
+        else:
+            total_kld, _, _ = kl_divergence(mu, logvar)
+            out = {"l1": l1, "kl": total_kld[0]}
         out["loss"] = out["l1"] + out["kl"] * cfg.kl_weight
         out["a_hat"], out["mu"], out["logvar"] = a_hat, mu, logvar
         return out

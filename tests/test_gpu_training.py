@@ -102,16 +102,27 @@ def _run_training_fixture(name, check_all):
     eng.load_state_dict(sd_np)
     eng.finalize()
     d = eng.device
-    out = eng.forward_train(torch.from_numpy(inp["qpos"]).to(d), torch.from_numpy(inp["image_u8"]).to(d),
-                            torch.from_numpy(inp["actions"]).to(d), torch.from_numpy(inp["is_pad"]).to(d),
-                            eps=torch.from_numpy(z["train.eps"]).to(d))
+    if cfg.vq:        # VQ-ACT: replay the reference's multinomial draw of the latent code (detr_vae.py:140)
+        out = eng.forward_train(torch.from_numpy(inp["qpos"]).to(d), torch.from_numpy(inp["image_u8"]).to(d),
+                                torch.from_numpy(inp["actions"]).to(d), torch.from_numpy(inp["is_pad"]).to(d),
+                                vq_code=torch.from_numpy(z["train.vq_code"]).view(B, cfg.vq_class, cfg.vq_dim).to(d))
+    else:
+        out = eng.forward_train(torch.from_numpy(inp["qpos"]).to(d), torch.from_numpy(inp["image_u8"]).to(d),
+                                torch.from_numpy(inp["actions"]).to(d), torch.from_numpy(inp["is_pad"]).to(d),
+                                eps=torch.from_numpy(z["train.eps"]).to(d))
     for k in ("l1", "kl", "loss"):
         got, exp = float(out[k]), float(z["train." + k][0])
         print(f"{name} {k}: hip {got:.6f} ref {exp:.6f}")
         assert abs(got - exp) <= 1e-4 * max(1.0, abs(exp)), k
     assert np.abs(out["a_hat"].cpu().numpy() - z["train.a_hat"]).max() <= 1e-4
-    assert np.abs(out["mu"].cpu().numpy() - z["train.mu"]).max() <= 1e-4
-    assert np.abs(out["logvar"].cpu().numpy() - z["train.logvar"]).max() <= 1e-4
+    if cfg.vq:
+        assert out["mu"] is None and out["logvar"] is None and float(out["kl"]) == 0.0
+        assert np.abs(out["probs"].cpu().numpy().reshape(-1) - z["train.vq_probs"].reshape(-1)).max() <= 1e-5
+        assert np.array_equal(out["binaries"].cpu().numpy().reshape(-1), z["train.vq_code"].reshape(-1))
+        assert abs(float(out["vq_discrepancy"]) - float(z["train.vq_discrepancy"][0])) <= 1e-5
+    else:
+        assert np.abs(out["mu"].cpu().numpy() - z["train.mu"]).max() <= 1e-4
+        assert np.abs(out["logvar"].cpu().numpy() - z["train.logvar"]).max() <= 1e-4
     eng.zero_grad()
     eng.backward(1.0)
     names = [str(n) for n in z["grad_names"]]
@@ -143,7 +154,7 @@ def _run_training_fixture(name, check_all):
     return eng, z, cfg, sd_np, inp
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_c3"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_c3", "tiny_vq"])
 def test_training_step_matches_reference_gradients(name):
     _run_training_fixture(name, True)
 

@@ -152,3 +152,25 @@ def test_oracle_vq_inference_matches_reference():
     with torch.no_grad():
         b = R.policy_call(sd, cfg, torch.from_numpy(inp["qpos"]), image, vq_sample=code.roll(1, dims=-1))
     assert np.abs(b.numpy() - z["infer.a_hat"]).max() > 1e-4
+
+
+def test_oracle_vq_training_matches_reference():
+    """VQ-ACT training (detr_vae.py:137-145, policy.py:307-318): the code the reference drew with torch.multinomial is
+    replayed as an input; losses (no KL), probabilities and the straight-through gradients agree."""
+    z, cfg = load_fixture("tiny_vq")
+    sd_np, inp = regenerate(z, cfg)
+    B = int(z["batch"])
+    torch.set_num_threads(1)
+    sd = {k: v.clone().requires_grad_(not W.is_buffer(k[len("model."):])) for k, v in torch_sd(sd_np).items()}
+    image = torch.from_numpy(W.u8_nhwc_to_f32_nchw(inp["image_u8"]))
+    code = torch.from_numpy(z["train.vq_code"]).view(B, cfg.vq_class, cfg.vq_dim)
+    out = R.policy_call(sd, cfg, torch.from_numpy(inp["qpos"]), image, torch.from_numpy(inp["actions"]),
+                        torch.from_numpy(inp["is_pad"]), None, vq_sample=code)
+    assert abs(float(out["l1"]) - float(z["train.l1"][0])) < 2e-5 and float(out["kl"]) == 0.0
+    assert abs(float(out["loss"]) - float(z["train.loss"][0])) < 2e-5
+    assert abs(float(out["vq_discrepancy"]) - float(z["train.vq_discrepancy"][0])) < 1e-6
+    out["loss"].backward()
+    for n in ("latent_proj.weight", "latent_out_proj.weight", "encoder.layers.0.linear1.weight", "action_head.weight"):
+        g = sd["model." + n].grad
+        exp = z["grad." + n].reshape(-1)
+        assert np.abs(sample_like(g.numpy(), z) - exp).max() <= 1e-5 * max(1.0, np.abs(exp).max()), n

@@ -255,16 +255,27 @@ def make_fixture(ref, name, cfg, batch, seed_w, seed_in, train=True, store_all_g
         torch.set_num_threads(1)
         loss_dict = pol(qpos, image, actions, is_pad)
         h.remove(); h2.remove(); h3.remove()
-        mu, logvar = cap["latent_info"][:, :cfg.latent_dim], cap["latent_info"][:, cfg.latent_dim:]
-        z_expect = mu + (logvar / 2).exp() * eps
-        assert torch.allclose(cap["z"], z_expect, atol=0, rtol=0), "eps replay mismatch"
+        if cfg.vq:
+            # the reference drew the code with torch.multinomial (detr_vae.py:140); the straight-through input of
+            # latent_out_proj is binaries - probs + probs = binaries up to rounding: recover the exact one-hot code
+            code = (cap["z"] > 0.5).float().view(batch, cfg.vq_class, cfg.vq_dim)
+            assert torch.equal(code.sum(-1), torch.ones(batch, cfg.vq_class))
+            probs = torch.softmax(cap["latent_info"].view(batch, cfg.vq_class, cfg.vq_dim), -1)
+            out["train.vq_code"], out["train.vq_probs"] = sub(code), sub(probs)
+            out["train.vq_discrepancy"] = np.array(loss_dict["vq_discrepancy"].detach().numpy(), dtype=np.float32).reshape(-1)
+            mu = logvar = None
+        else:
+            mu, logvar = cap["latent_info"][:, :cfg.latent_dim], cap["latent_info"][:, cfg.latent_dim:]
+            z_expect = mu + (logvar / 2).exp() * eps
+            assert torch.allclose(cap["z"], z_expect, atol=0, rtol=0), "eps replay mismatch"
         loss_dict["loss"].backward()
         torch.set_num_threads(nthreads)
-        out["train.eps"] = sub(eps)
-        out["train.mu"], out["train.logvar"] = sub(mu), sub(logvar)
+        if not cfg.vq:
+            out["train.eps"] = sub(eps)
+            out["train.mu"], out["train.logvar"] = sub(mu), sub(logvar)
         out["train.a_hat"] = sub(cap["a_hat"])
         for k in ("l1", "kl", "loss"):
-            out["train." + k] = np.array(loss_dict[k].detach().numpy(), dtype=np.float32).reshape(-1)
+            out["train." + k] = np.array(torch.as_tensor(loss_dict[k]).detach().numpy(), dtype=np.float32).reshape(-1)
         gnames, gnorm, gsum, gnone = [], [], [], []
         sel = ["action_head.weight", "action_head.bias", "latent_proj.weight", "latent_out_proj.weight",
                "encoder.layers.0.linear1.weight", "encoder_action_proj.weight", "input_proj.weight",
@@ -311,7 +322,8 @@ def cross_check_oracle(cfg, out, sd_np, inp, tol=2e-5):
     if "train.loss" in out:
         with torch.no_grad():
             r = R.policy_call(sd, cfg, qpos, image, torch.from_numpy(inp["actions"]), torch.from_numpy(inp["is_pad"]),
-                              torch.from_numpy(out["train.eps"]))
+                              None if cfg.vq else torch.from_numpy(out["train.eps"]),
+                              vq_sample=torch.from_numpy(out["train.vq_code"]).view(-1, cfg.vq_class, cfg.vq_dim) if cfg.vq else None)
         for k in ("l1", "kl", "loss"):
             dd = abs(float(r[k]) - float(out["train." + k][0]))
             print(f"  oracle {k}: {float(r[k]):.6f} ref {float(out['train.'+k][0]):.6f} diff {dd:.2e}")
@@ -334,8 +346,8 @@ def main():
         "full3": dict(cfg=ACTConfig(camera_names=["top", "left_wrist", "right_wrist"]), batch=1, seed_w=3, seed_in=99,
                       train=False, store_all_grads=False, stage_step=8192),
         # VQ-ACT inference (detr_vae.py:155-156): latent = latent_out_proj(given one-hot code)
-        "tiny_vq": dict(cfg=tiny_config(vq=True, vq_class=4, vq_dim=8), batch=3, seed_w=9, seed_in=21, train=False,
-                        store_all_grads=False, stage_step=None),
+        "tiny_vq": dict(cfg=tiny_config(vq=True, vq_class=4, vq_dim=8), batch=3, seed_w=9, seed_in=21, train=True,
+                        store_all_grads=True, stage_step=None),
     }
     for name, j in jobs.items():
         if args.only and name != args.only:
