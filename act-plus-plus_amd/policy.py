@@ -129,6 +129,15 @@ class ACTPolicy:
 
     @torch.no_grad()
     def vq_encode(self, qpos, actions, is_pad):
-        """reference policy.py:336-341 (the codes the latent prior is trained on): needs the CVAE encoder alone, which
-        this library only runs as part of a full training forward."""
-        raise NotImplementedError("vq_encode / the latent prior model are outside the accelerated path (SURVEY §8 f4)")
+        """reference policy.py:336-341: the sampled one-hot codes [B, vq_class, vq_dim] of the CVAE encoder (what the
+        latent prior model is trained on).  The encoder does not look at the images, so a zero image batch is fed; the
+        library runs its whole training forward for this (correct, not economical: the prior is outside the hot path)."""
+        if not self.vq:
+            raise ValueError("vq_encode needs a vq policy")
+        cfg = self.cfg
+        B = qpos.shape[0]
+        img = torch.zeros((B, cfg.num_cams, cfg.image_h, cfg.image_w, 3), dtype=torch.uint8, device=qpos.device)
+        self._drop_step = getattr(self, "_drop_step", 0) + 1
+        out = self.model.forward_train(qpos, img, actions, is_pad, dropout_p=0.0,
+                                       dropout_seed=(self.dropout_seed << 20) + self._drop_step)
+        return out["binaries"]

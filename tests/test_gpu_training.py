@@ -264,3 +264,31 @@ def test_training_gradients_with_dropout_by_finite_differences():
         print(f"{k}{list(idx)}: analytic {ga:+.5f} finite-diff {fd:+.5f} rel.err {err:.3f}")
         worst = max(worst, err)
         assert err < 0.08, (k, ga, fd)
+
+
+def test_vq_device_drawn_code():
+    """without a given code the library draws it itself (inverse CDF on the counter-based generator): one-hot per class,
+    a pure function of the seed, and distributed like the softmax probabilities (detr_vae.py:139-140)"""
+    z, cfg = load_fixture("tiny_vq")
+    sd_np, inp = regenerate(z, cfg)
+    B = int(z["batch"])
+    eng = ACTEngine(cfg, max_batch=B, training=True)
+    eng.load_state_dict(sd_np)
+    eng.finalize()
+    d = eng.device
+    args = (torch.from_numpy(inp["qpos"]).to(d), torch.from_numpy(inp["image_u8"]).to(d),
+            torch.from_numpy(inp["actions"]).to(d), torch.from_numpy(inp["is_pad"]).to(d))
+    a = eng.forward_train(*args, dropout_seed=7)
+    b = eng.forward_train(*args, dropout_seed=7)
+    assert torch.equal(a["binaries"], b["binaries"]) and torch.equal(a["a_hat"], b["a_hat"])
+    assert torch.equal(a["binaries"].sum(-1), torch.ones(B, cfg.vq_class, device=d))
+    assert set(a["binaries"].unique().tolist()) <= {0.0, 1.0}
+    probs = a["probs"].cpu().double()
+    n, counts = 400, torch.zeros(B, cfg.vq_class, cfg.vq_dim, dtype=torch.float64)
+    for s in range(n):
+        counts += eng.forward_train(*args, dropout_seed=1000 + s)["binaries"].cpu().double()
+    freq = counts / n
+    assert float((freq - probs).abs().max()) < 4.5 * float((probs * (1 - probs) / n).sqrt().max()) + 1e-3
+    eng.zero_grad()
+    eng.backward(1.0)                                   # the straight-through path runs with a drawn code too
+    assert float(eng.grad("latent_proj.weight").abs().max()) > 0
