@@ -55,7 +55,7 @@ class AttnDesc(C.Structure):
         ("kpm", C.c_void_p), ("kpm_bs", C.c_int64), ("lse", C.c_void_p),
         ("B", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("HD", C.c_int32),
         ("scale", C.c_float), ("ws", C.c_void_p), ("ws_floats", C.c_int64),
-        ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("prec", C.c_int32),
+        ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("prec", C.c_int32), ("causal", C.c_int32),
     ]
 
 
@@ -94,6 +94,7 @@ def load():
         "actmi_ensemble_step": ([vp, vp, vp, f64, vp, vp, i32, i32, i32, vp], i32),
         "actmi_op_gemm": ([C.POINTER(GemmDesc), vp], i32),
         "actmi_op_split16": ([vp, vp, C.c_int64, C.c_float, vp], i32),
+        "actmi_op_sample_onehot": ([vp, i32, i32, C.c_float, C.c_uint64, vp, vp, vp], i32),
         "actmi_op_pow2_scale": ([vp, C.c_int64, i32, i32, vp, vp], i32),
         "actmi_op_attention": ([C.POINTER(AttnDesc), vp], i32),
         "actmi_op_layernorm": ([vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp], i32),

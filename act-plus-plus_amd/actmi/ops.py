@@ -52,7 +52,7 @@ def gemm(A, W, bias=None, scale=None, res=None, res_mod=0, relu=False, a_add=Non
     d.bias = bias.data_ptr() if bias is not None else None
     if res is not None:
         d.res, d.ldres, d.res_mod = res.data_ptr(), res.stride(0), res_mod
-    d.relu = 1 if relu else 0
+    d.relu = 2 if relu == "gelu" else (1 if relu else 0)
     d.C, d.ldc = out.data_ptr(), out.stride(0)
     d.rowmap = rowmap.data_ptr() if rowmap is not None else None
     d.M, d.N, d.K, d.groups = M, N, K, 1
@@ -91,6 +91,18 @@ def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1
     return out
 
 
+def sample_onehot(logits, temperature=1.0, seed=0, want_probs=False):
+    """one categorical draw per row of logits [n, V] -> one-hot [n, V] (device-side inverse CDF, counter-based generator)."""
+    lib = L.load()
+    logits = logits.contiguous()
+    n, V = logits.shape
+    code = torch.empty_like(logits)
+    probs = torch.empty_like(logits) if want_probs else None
+    L.check(lib.actmi_op_sample_onehot(_p(logits), n, V, float(temperature), C.c_uint64(int(seed)), _p(probs), _p(code),
+                                       L.current_stream_ptr()), None, "op_sample_onehot")
+    return (code, probs) if want_probs else code
+
+
 def conv3x3_c64(x, w_ohwi, scale=None, bias=None, res=None, relu=False, w_scale=256.0):
     """direct 3x3/s1/p1 conv, 64 -> 64 channels, f16x3: x [G,B,H,W,64]; w_ohwi [G,64,3,3,64]; returns [G,B,H,W,64]."""
     lib = L.load()
@@ -106,7 +118,8 @@ def conv3x3_c64(x, w_ohwi, scale=None, bias=None, res=None, relu=False, w_scale=
     return out
 
 
-def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False, split=True, drop_p=0.0, drop_seed=0, prec=None):
+def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False, split=True, drop_p=0.0, drop_seed=0, prec=None,
+              causal=False):
     """q [B,Nq,D] (or [Nq,D] when q_shared), k/v [B,Nk,D] (views with row stride allowed); returns [B,Nq,D]."""
     lib = L.load()
     B, Nk, D = k.shape
@@ -129,6 +142,7 @@ def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False, split=T
     d.scale = 1.0 / (hd ** 0.5)
     d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)
     d.prec = PREC[prec]
+    d.causal = 1 if causal else 0
     L.check(lib.actmi_op_attention(C.byref(d), L.current_stream_ptr()), None, "op_attention")
     return (out, lse) if want_lse else out
 

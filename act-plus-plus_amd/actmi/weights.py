@@ -262,3 +262,21 @@ def fixture_sample(a: np.ndarray, max_elems: int) -> np.ndarray:
     stride = -(-flat.size // max_elems)
     stride += (stride % 2 == 0)
     return flat[::stride].copy()
+
+
+def generate_latent_model_state_dict(spec, seed: int):
+    """Deterministic weights for the VQ latent prior (actmi/latent_model.py:latent_model_spec): LayerNorm gains near 1,
+    biases small, matrices ~ N(0, 1/fan_in)."""
+    out = {}
+    for k, shp in spec.items():
+        base = normal(seed, "lm:" + k, int(np.prod(shp))).astype(np.float32).reshape(shp)
+        is_gain = k.endswith("ln_1.weight") or k.endswith("ln_2.weight") or (k.startswith("attention_blocks.") and
+                                                                               k.count(".") == 2 and k.endswith(".weight"))
+        if is_gain:
+            v = 1.0 + 0.1 * base
+        elif k.endswith("bias"):
+            v = 0.1 * base
+        else:
+            v = base / np.float32(np.sqrt(shp[-1]))
+        out[k] = np.ascontiguousarray(v, dtype=np.float32)
+    return out

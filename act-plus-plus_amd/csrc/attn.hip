@@ -127,6 +127,11 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p, int nsplit, i
                     for (int e = 0; e < 16; ++e)
                         if (s_dead[sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh]) S[e] = -INFINITY;
                 }
+                if (p.causal) {          // key j is visible to query i only for j <= i (nn.MultiheadAttention attn_mask = triu(1))
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (kb + (e & 3) + 8 * (e >> 2) + 4 * lh > q) S[e] = -INFINITY;
+                }
                 float mt = S[0];
 #pragma unroll
                 for (int e = 1; e < 16; ++e) mt = fmaxf(mt, S[e]);
@@ -363,6 +368,11 @@ __global__ __launch_bounds__(256) void attn_f16x3_kernel(AttnArgs p, int nsplit,
                     for (int e = 0; e < 16; ++e)
                         if (s_dead[sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh]) S[e] = -INFINITY;
                 }
+                if (p.causal) {          // key j is visible to query i only for j <= i (nn.MultiheadAttention attn_mask = triu(1))
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (kb + (e & 3) + 8 * (e >> 2) + 4 * lh > q) S[e] = -INFINITY;
+                }
                 float mt = S[0];
 #pragma unroll
                 for (int e = 1; e < 16; ++e) mt = fmaxf(mt, S[e]);
@@ -489,6 +499,7 @@ int launch_attention(const AttnArgs& a, hipStream_t st, std::string* err) {
     auto fail = [&](const char* m) { if (err) *err = std::string("attention: ") + m; return -2; };
     if (a.B <= 0 || a.Nq <= 0) return 0;
     if (a.Nk <= 0) return fail("Nk must be positive");
+    if (a.causal && a.Nq != a.Nk) return fail("causal needs Nq == Nk");
     if ((a.q_rs & 3) || (a.k_rs & 3) || (a.v_rs & 3) || (a.o_rs & 3) || (a.q_bs & 3) || (a.k_bs & 3) || (a.v_bs & 3) ||
         (a.o_bs & 3))
         return fail("strides must be multiples of 4 floats");

@@ -578,22 +578,22 @@ int launch_reparam(const float* latent_info, const float* eps, float* z, float* 
 // generator; the straight-through estimator makes latent_input = latent_out_proj(code) in the forward pass and routes
 // d(code) to the probabilities in the backward pass.
 __global__ void vq_code_kernel(const float* __restrict__ logits, const float* __restrict__ code_in, uint64_t seed,
-                               float* __restrict__ probs, float* __restrict__ code, int n, int VD) {
+                               float* __restrict__ probs, float* __restrict__ code, int n, int VD, float inv_temp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (sample, class)
     if (i >= n) return;
     const float* lg = logits + (int64_t)i * VD;
     float m = -INFINITY;
-    for (int j = 0; j < VD; ++j) m = fmaxf(m, lg[j]);
+    for (int j = 0; j < VD; ++j) m = fmaxf(m, lg[j] * inv_temp);
     float s = 0.f;
-    for (int j = 0; j < VD; ++j) s += expf(lg[j] - m);
+    for (int j = 0; j < VD; ++j) s += expf(lg[j] * inv_temp - m);
     const float inv = 1.f / s;
     int pick = VD - 1;
     const float u = code_in ? 0.f : actmi_u01(seed, (uint64_t)i);
     float cum = 0.f;
     bool found = false;
     for (int j = 0; j < VD; ++j) {
-        const float pj = expf(lg[j] - m) * inv;
-        probs[(int64_t)i * VD + j] = pj;
+        const float pj = expf(lg[j] * inv_temp - m) * inv;
+        if (probs) probs[(int64_t)i * VD + j] = pj;
         cum += pj;
         if (!found && cum > u) { pick = j; found = true; }
     }
@@ -612,9 +612,10 @@ __global__ void vq_bwd_kernel(const float* __restrict__ probs, const float* __re
 }
 
 int launch_vq_code(const float* logits, const float* code_in, uint64_t seed, float* probs, float* code, int B, int VC, int VD,
-                   hipStream_t st) {
+                   hipStream_t st, float temperature) {
     const int n = B * VC;
-    hipLaunchKernelGGL(vq_code_kernel, dim3((n + 255) / 256), dim3(256), 0, st, logits, code_in, seed, probs, code, n, VD);
+    hipLaunchKernelGGL(vq_code_kernel, dim3((n + 255) / 256), dim3(256), 0, st, logits, code_in, seed, probs, code, n, VD,
+                       1.f / temperature);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -139,6 +139,13 @@ int actmi_op_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, vo
     return launch_pow2_scale(x, ld, M, N, out, S(stream)) == 0 ? 0 : ACTMI_E_LAUNCH;
 }
 
+int actmi_op_sample_onehot(const float* logits, int n, int V, float temperature, uint64_t seed, float* probs, float* code,
+                           void* stream) {
+    g_op_error.clear();
+    if (!logits || !code || n < 1 || V < 1 || !(temperature > 0.f)) { g_op_error = "sample_onehot: bad argument"; return ACTMI_E_INVALID; }
+    return launch_vq_code(logits, nullptr, seed, probs, code, n, 1, V, S(stream), temperature) == 0 ? 0 : ACTMI_E_LAUNCH;
+}
+
 int actmi_op_attention(const actmi_attn_desc* d, void* stream) {
     if (!d) return ACTMI_E_INVALID;
     g_op_error.clear();

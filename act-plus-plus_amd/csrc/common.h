@@ -105,7 +105,7 @@ int launch_reparam(const float* latent_info, const float* eps, float* z, float* 
 int launch_reparam_kl_bwd(const float* latent_info, const float* eps, const float* dz, float* d_latent_info, int B, int L,
                           float klw_scaled, hipStream_t st);
 int launch_vq_code(const float* logits, const float* code_in, uint64_t seed, float* probs, float* code, int B, int VC, int VD,
-                   hipStream_t st);
+                   hipStream_t st, float temperature = 1.f);
 int launch_vq_bwd(const float* probs, const float* g, float* dlogits, int B, int VC, int VD, hipStream_t st);
 int launch_adamw(float* p, const float* g, float* m, float* v, const uint8_t* group, int64_t n, float lr, float lr_bb,
                  float wd, float b1, float b2, float eps, int64_t step, hipStream_t st);

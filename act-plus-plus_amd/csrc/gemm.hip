@@ -703,7 +703,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
                         (!has_mask || (int64_t)p.M * ldmask < (int64_t)1 << 31) &&
                         (int64_t)p.M * p.ldc < (int64_t)1 << 31 && (!has_res || (int64_t)p.M * p.ldres < (int64_t)1 << 31);
     if (simple) {
-        const bool relu = p.relu != 0;
+        const bool relu = p.relu == 1, gelu = p.relu == 2;
         // Vector form: the wave's accumulator tile goes through the (now idle) LDS stage one 32-row band at a time and
         // leaves as 16-byte stores, a row segment of WN floats per WN/4 lanes -- 4x fewer store instructions, each
         // covering whole 128-byte lines.  (The scalar form below writes 4 bytes per lane; its store burst was measured
@@ -748,6 +748,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                         }
+                        if (gelu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
+                        }
                         *reinterpret_cast<f32x4*>(C + (uint32_t)(m * (int)p.ldc + ncol)) = v;
                     }
                 }
@@ -780,6 +784,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel
                     if (has_res) v += rv[e];
                     if (has_mask && nok && m < p.M) { if (!(mask[(uint32_t)(m * (int)ldmask + n)] > 0.f)) v = 0.f; }
                     v = relu ? fmaxf(v, 0.f) : v;
+                    if (gelu) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
                     if (nok && m < p.M) C[(uint32_t)(m * (int)p.ldc + n)] = v;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -936,6 +941,8 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t st, std::string* err) {
     if (a.K <= 0) return fail("K must be positive");
     if (((uintptr_t)a.A & 15) || ((uintptr_t)a.Bw & 15)) return fail("A/B must be 16-byte aligned");
     if (a.splitk > 1 && (a.bias || a.res || a.mask || a.relu || a.C2 || a.scale)) return fail("split-K supports a plain accumulate only");
+    if (a.relu == 2 && (a.rowmap || a.C2 || a.drop_p > 0.f || a.res_mod != 0)) return fail("GELU is only available in the plain epilogue");
+    if (a.relu < 0 || a.relu > 2) return fail("bad activation");
     if (a.C2 && !a.scale2) return fail("C2 needs scale2");
     int amode, bmode = a.tb;
     if (a.ta) {

@@ -80,8 +80,8 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
     """reference imitate_episodes.py:228-526, batched + sharded.  Returns (success_rate, avg_return).
 
     VQ-ACT: the reference samples the latent code from its prior model each query
-    (``latent_model.generate(1, temperature=1)``, imitate_episodes.py:252-262,393-394).  That model is outside this
-    path; a caller with a prior passes ``vq_sampler(n) -> [n, vq_class, vq_dim]`` one-hot codes."""
+    (``latent_model.generate(1, temperature=1)``, imitate_episodes.py:252-262,393-394): ``actmi.latent_model`` mirrors it
+    on the library's kernels; ``vq_sampler(n) -> [n, vq_class, vq_dim]`` overrides the source of the codes."""
     set_seed(1000)
     ckpt_dir = config["ckpt_dir"]
     state_dim = config["state_dim"]
@@ -118,7 +118,23 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
 
     use_vq = bool(policy_config.get("vq", False))
     if use_vq and vq_sampler is None:
-        raise NotImplementedError("VQ-ACT evaluation needs vq_sampler (the latent prior model is outside the accelerated path)")
+        # reference imitate_episodes.py:252-262: the latent prior, weights from latent_model_last.ckpt next to the policy
+        from actmi.latent_model import LatentModelTransformer, latent_model_spec
+        from actmi.weights import generate_latent_model_state_dict
+        vq_dim, vq_class = policy_config["vq_dim"], policy_config["vq_class"]
+        latent_model = LatentModelTransformer(vq_dim, vq_dim, vq_class, device=str(dev))
+        lm_path = os.path.join(ckpt_dir, "latent_model_last.ckpt")
+        if os.path.isfile(lm_path):
+            latent_model.load_state_dict(torch.load(lm_path, weights_only=True))
+        else:
+            if verbose:
+                print(f"no latent model at {lm_path}: sampling codes from a random-init prior")
+            latent_model.load_state_dict(generate_latent_model_state_dict(latent_model_spec(vq_dim, vq_dim, vq_class), 0))
+        _draws = [0]
+
+        def vq_sampler(n):                       # imitate_episodes.py:393: latent_model.generate(1, temperature=1, x=None)
+            _draws[0] += 1
+            return latent_model.generate(n, temperature=1, x=None, seed=1000 * rank + _draws[0])
     num_queries = policy_config["num_queries"]
     query_frequency = 1 if temporal_agg else num_queries
     action_dim = policy_config.get("action_dim", 16)

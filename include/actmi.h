@@ -80,7 +80,7 @@ typedef struct actmi_gemm_desc {
     const float* res;          /* residual or NULL */
     int64_t ldres;
     int32_t res_mod;
-    int32_t relu;
+    int32_t relu;              /* activation: 0 none, 1 ReLU, 2 GELU (exact erf form, nn.GELU default) */
     float* C;
     int64_t ldc;
     const int32_t* rowmap;
@@ -151,6 +151,8 @@ typedef struct actmi_attn_desc {
     uint64_t drop_seed;
     /* product precision, as in actmi_gemm_desc.prec (0 = ACTMI_GEMM_PREC from the environment, else native fp32) */
     int32_t prec;
+    /* 1: causal mask, key j visible to query i only for j <= i (needs Nq == Nk) */
+    int32_t causal;
 } actmi_attn_desc;
 
 int actmi_version(void);
@@ -210,6 +212,10 @@ int actmi_op_split16(const float* src, float* dst, int64_t nfloats, float scale,
 /* out[0] = the power of two s with max|x| * s in [2^13, 2^14) over the M x N matrix x (row stride ld); 1 if x is all
  * zero or not finite.  out[1] is scratch and must be zero before the first use (the op leaves it zero).  For actmi_gemm_desc.a_scale_dev / b_scale_dev. */
 int actmi_op_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, void* stream);
+/* one categorical draw per row: code[i] = one_hot(sample(softmax(logits[i] / temperature))) by inverse CDF on the
+ * counter-based generator (replaces torch.multinomial in detr_vae.py:140 and latent_model.py:68-69); probs may be NULL */
+int actmi_op_sample_onehot(const float* logits, int n, int V, float temperature, uint64_t seed, float* probs, float* code,
+                           void* stream);
 int actmi_op_attention(const actmi_attn_desc* d, void* stream);
 int actmi_op_layernorm(const float* x, const float* res, int res_mod, const float* w, const float* b, const float* w2,
                        const float* b2, float* y, int M, int D, float eps, void* stream);

@@ -288,6 +288,33 @@ def policy_call(sd, cfg, qpos, image, actions=None, is_pad=None, eps=None, dropo
 
 
 # ------------------------------------------------------------------------------------------------
+# detr/models/latent_model.py
+# ------------------------------------------------------------------------------------------------
+
+def latent_model_forward(sd, x, num_head=8, num_layer=3):
+    """Latent_Model_Transformer.forward in eval mode (latent_model.py:50-56 over the block of :24-31): residuals branch
+    off the normalised activations, causal self-attention, exact GELU."""
+    T = x.shape[1]
+    h = F.linear(x, sd["input_layer.weight"], sd["input_layer.bias"]) + sd["weight_pos_embed.weight"][:T]
+    D = h.shape[-1]
+    mask = torch.triu(torch.ones(T, T, dtype=torch.bool), diagonal=1)
+    for i in range(1, num_layer + 1):
+        p = f"attention_blocks.{i}."
+        h = F.layer_norm(h, (D,), sd[p + "ln_1.weight"], sd[p + "ln_1.bias"])
+        a, _ = F.multi_head_attention_forward(
+            h.transpose(0, 1), h.transpose(0, 1), h.transpose(0, 1), D, num_head, sd[p + "attn.in_proj_weight"],
+            sd[p + "attn.in_proj_bias"], None, None, False, 0.0, sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"],
+            training=False, attn_mask=mask, need_weights=False)
+        h = h + a.transpose(0, 1)
+        h = F.layer_norm(h, (D,), sd[p + "ln_2.weight"], sd[p + "ln_2.bias"])
+        m = F.gelu(F.linear(h, sd[p + "mlp.0.weight"], sd[p + "mlp.0.bias"]))
+        h = h + F.linear(m, sd[p + "mlp.2.weight"], sd[p + "mlp.2.bias"])
+    p = f"attention_blocks.{num_layer + 1}."
+    h = F.layer_norm(h, (D,), sd[p + "weight"], sd[p + "bias"])
+    return F.linear(h, sd["output_layer.weight"], sd["output_layer.bias"])
+
+
+# ------------------------------------------------------------------------------------------------
 # imitate_episodes.py
 # ------------------------------------------------------------------------------------------------
 

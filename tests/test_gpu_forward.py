@@ -173,3 +173,41 @@ def test_vq_inference_matches_reference_golden(prec):
         eng.forward_infer(qpos, img)                      # a vq policy needs its code
     other = eng.forward_infer(qpos, img, vq_sample=code.roll(1, dims=-1)).cpu().numpy()
     assert np.abs(other - z["infer.a_hat"]).max() > 1e-4
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_latent_prior_matches_reference_golden(prec):
+    """VQ-ACT prior (latent_model.py:35-72) on the library's kernels: logits against the reference module's, and the
+    structural contract of generate()."""
+    from test_oracle_golden import _latent_prior_fixture
+    from actmi.latent_model import LatentModelTransformer
+    z, sd, vq_dim, vq_class = _latent_prior_fixture()
+    m = LatentModelTransformer(vq_dim, vq_dim, vq_class, gemm_prec=prec).load_state_dict(sd)
+    logits = m(torch.from_numpy(z["x"])).cpu().numpy()
+    err = np.abs(logits - z["logits"]).max()
+    print(f"latent prior [{prec}]: max|logits - ref| = {err:.3e}")
+    assert err <= 1e-4
+    # causality: logits at position t do not depend on later inputs
+    x2 = torch.from_numpy(z["x"]).clone()
+    x2[:, -1] = 0.0
+    assert np.array_equal(m(x2).cpu().numpy()[:, :-1], logits[:, :-1])
+    # generate(): seq_len one-hot codes per sample, reproducible in the seed, first step = the draw from forward(zeros)
+    a = m.generate(5, temperature=1.0, seed=3)
+    assert tuple(a.shape) == (5, vq_class, vq_dim) and torch.equal(a.sum(-1), torch.ones(5, vq_class, device=a.device))
+    assert torch.equal(a, m.generate(5, temperature=1.0, seed=3)) and not torch.equal(a, m.generate(5, temperature=1.0, seed=4))
+    cold = m.generate(5, temperature=1e-3, seed=9)               # near-greedy: argmax of the step logits
+    step0 = m(torch.zeros(5, 1, vq_dim))[:, -1]
+    assert torch.equal(cold[:, 0].argmax(-1), step0.argmax(-1))
+
+
+def test_sample_onehot_distribution():
+    from actmi import ops
+    g = torch.Generator().manual_seed(2)
+    logits = torch.randn(4, 6, generator=g).cuda()
+    p = torch.softmax(logits.double() / 0.7, -1).cpu()
+    n, cnt = 2000, torch.zeros(4, 6, dtype=torch.float64)
+    for s in range(n):
+        cnt += ops.sample_onehot(logits, temperature=0.7, seed=s).cpu().double()
+    assert float((cnt / n - p).abs().max()) < 4.5 * float((p * (1 - p) / n).sqrt().max())
+    code, probs = ops.sample_onehot(logits, temperature=0.7, seed=1, want_probs=True)
+    assert float((probs.cpu().double() - p).abs().max()) < 1e-6 and torch.equal(code.sum(-1), torch.ones(4).cuda())

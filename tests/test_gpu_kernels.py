@@ -206,6 +206,31 @@ def test_attention(B, H, Nq, Nk, hd, masked, shared, prec):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("B,H,N,hd", [(3, 8, 33, 32), (2, 4, 4, 16), (2, 8, 130, 64)])
+def test_attention_causal(B, H, N, hd, prec):
+    """causal mask (attn_mask = triu(ones, 1) of latent_model.py:26): key j visible to query i only for j <= i"""
+    g = torch.Generator().manual_seed(N)
+    D = H * hd
+    q, k, v = (torch.randn(B, N, D, generator=g) for _ in range(3))
+    qq, kk, vv = (x.double().view(B, N, H, hd).transpose(1, 2) for x in (q, k, v))
+    s = qq @ kk.transpose(-1, -2) / hd ** 0.5
+    s = s.masked_fill(torch.triu(torch.ones(N, N, dtype=torch.bool), diagonal=1), float("-inf"))
+    exp = (torch.softmax(s, -1) @ vv).transpose(1, 2).reshape(B, N, D)
+    d = dev()
+    got = ops.attention(q.to(d), k.to(d), v.to(d), H, causal=True, prec=prec)
+    assert rel_err(got, exp) < 3e-6
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_gemm_gelu_epilogue(prec):
+    g = torch.Generator().manual_seed(8)
+    A, W, b = torch.randn(100, 256, generator=g), torch.randn(1024, 256, generator=g) / 16, torch.randn(1024, generator=g)
+    exp = F.gelu(F.linear(A.double(), W.double(), b.double()))
+    got = ops.gemm(A.to(dev()), W.to(dev()), bias=b.to(dev()), relu="gelu", prec=prec)
+    assert rel_err(got, exp) < 2e-6
+
+
+@pytest.mark.parametrize("prec", PRECS)
 def test_attention_online_softmax_rescale_branch(prec):
     """Force the running max to jump late: one key dominates in the LAST tile (rule: a rare branch needs its own test)."""
     B, H, Nq, Nk, hd = 1, 1, 40, 200, 64

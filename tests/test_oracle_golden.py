@@ -174,3 +174,23 @@ def test_oracle_vq_training_matches_reference():
         g = sd["model." + n].grad
         exp = z["grad." + n].reshape(-1)
         assert np.abs(sample_like(g.numpy(), z) - exp).max() <= 1e-5 * max(1.0, np.abs(exp).max()), n
+
+
+def _latent_prior_fixture():
+    import hashlib, os
+    from actmi.latent_model import latent_model_spec
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "latent_prior.npz"))
+    vq_dim, vq_class = int(z["vq_dim"]), int(z["vq_class"])
+    spec = latent_model_spec(vq_dim, vq_dim, vq_class)
+    sd = W.generate_latent_model_state_dict(spec, int(z["seed_w"]))
+    for k in ("output_layer.weight", "attention_blocks.2.mlp.0.weight"):
+        assert hashlib.sha256(np.ascontiguousarray(sd[k]).tobytes()).hexdigest() == str(z["sha:" + k]), k
+    return z, sd, vq_dim, vq_class
+
+
+def test_oracle_latent_prior_matches_reference():
+    """Latent_Model_Transformer.forward (latent_model.py:50-56), fixture from the reference's own module in eval mode"""
+    z, sd, vq_dim, vq_class = _latent_prior_fixture()
+    with torch.no_grad():
+        lo = R.latent_model_forward({k: torch.from_numpy(v) for k, v in sd.items()}, torch.from_numpy(z["x"]))
+    assert np.abs(lo.numpy() - z["logits"]).max() < 2e-5

@@ -104,6 +104,7 @@ def import_reference():
     ns.tr = importlib.import_module("detr.models.transformer")
     ns.bb = importlib.import_module("detr.models.backbone")
     ns.pe = importlib.import_module("detr.models.position_encoding")
+    ns.lm = importlib.import_module("detr.models.latent_model")
     return ns
 
 
@@ -330,6 +331,42 @@ def cross_check_oracle(cfg, out, sd_np, inp, tol=2e-5):
             assert dd < 5e-5 * max(1.0, abs(float(r[k])))
 
 
+def make_latent_prior_fixture(ref):
+    """VQ-ACT prior: the reference's Latent_Model_Transformer (latent_model.py:35-56) in eval mode on one-hot prefixes."""
+    from actmi import weights as W
+    from actmi.latent_model import latent_model_spec
+    vq_dim, vq_class, n = 8, 4, 3
+    m = ref.lm.Latent_Model_Transformer(vq_dim, vq_dim, vq_class)
+    spec = latent_model_spec(vq_dim, vq_dim, vq_class)
+    ref_sd = m.state_dict()
+    assert list(ref_sd.keys()) == list(spec.keys()), "latent model key order differs from reference"
+    for k, shp in spec.items():
+        assert tuple(ref_sd[k].shape) == tuple(shp), k
+    sd_np = W.generate_latent_model_state_dict(spec, 31)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    m.eval()
+    pick = (W.uniform01(32, "lm:x", n * vq_class) * vq_dim).astype(np.int64).reshape(n, vq_class)
+    x = np.zeros((n, vq_class, vq_dim), dtype=np.float32)          # row 0 = the all-zero start token of generate()
+    for b in range(n):
+        for t in range(1, vq_class):
+            x[b, t, min(pick[b, t], vq_dim - 1)] = 1.0
+    with torch.no_grad():
+        logits = m(torch.from_numpy(x))
+    out = {"vq_dim": np.array(vq_dim), "vq_class": np.array(vq_class), "seed_w": np.array(31), "x": x, "logits": logits.numpy(),
+           "sha:output_layer.weight": np.array(sha(sd_np["output_layer.weight"])),
+           "sha:attention_blocks.2.mlp.0.weight": np.array(sha(sd_np["attention_blocks.2.mlp.0.weight"]))}
+    path = os.path.join(GOLD, "latent_prior.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path)/1024:.1f} KB)")
+    sys.path.insert(0, ROOT)
+    from oracle import act_ref as R
+    with torch.no_grad():
+        lo = R.latent_model_forward({k: torch.from_numpy(v) for k, v in sd_np.items()}, torch.from_numpy(x))
+    d = float((lo - logits).abs().max())
+    print(f"  oracle vs reference latent prior: max|logit diff| = {d:.3e}")
+    assert d < 2e-5
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -349,6 +386,9 @@ def main():
         "tiny_vq": dict(cfg=tiny_config(vq=True, vq_class=4, vq_dim=8), batch=3, seed_w=9, seed_in=21, train=True,
                         store_all_grads=True, stage_step=None),
     }
+    if not args.only or args.only == "latent_prior":
+        print("== latent_prior")
+        make_latent_prior_fixture(ref)
     for name, j in jobs.items():
         if args.only and name != args.only:
             continue
