@@ -1,0 +1,295 @@
+"""Input pipeline of the ACT training loop: the reference's ``utils.py`` dataset logic feeding the
+accelerated step.
+
+Mirrors, with the reference's names and argument meaning:
+``get_norm_stats`` (utils.py:176-224), ``find_all_hdf5`` (:226-235), ``BatchSampler`` (:237-247),
+``EpisodicDataset`` (:41-174; ``_locate_transition``, ``__getitem__``) and ``load_data`` (:249-301).
+
+Differences, all on the host side of the step:
+* images stay **u8 NHWC** ``[C, H, W, 3]`` (the engine's fast input format; the ``/255`` and the ImageNet normalisation are
+  fused into the conv1 loader) — ``f32_images=True`` reproduces the reference contract (f32 ``[C, 3, H, W]`` in [0, 1]);
+* batches are collated into **pinned** buffers and handed to the device by ``DevicePrefetcher`` on a side stream while
+  the previous step computes (the reference moves 944 MB of f32 images per batch-64 step synchronously);
+* episode files are opened through ``open_episode``: HDF5 via ``h5py`` when it is importable (the reference's format:
+  ``/observations/qpos``, ``/observations/qvel``, ``/observations/images/<cam>``, ``/action``, optional ``/base_action``,
+  attrs ``sim`` / ``compress``), or ``.npz`` files with the same keys (``attrs_sim`` / ``attrs_compress`` entries) — what
+  the tests use, since neither h5py nor cv2 exists in the build container.  Compressed images (cv2.imdecode) and the
+  Diffusion-only augmentations (torchvision transforms) are therefore not handled: **parity unpinned** for those two
+  branches; everything else is checked against an independent restatement in ``tests/test_data_pipeline_cpu.py``."""
+import fnmatch
+import os
+
+import numpy as np
+import torch
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# episode files
+# ---------------------------------------------------------------------------------------------------------------------
+class _NpzEpisode:
+    """read-only view of an ``.npz`` episode with the HDF5 key layout"""
+
+    def __init__(self, path):
+        self._z = np.load(path, allow_pickle=False)
+        self.attrs = {k[len("attrs_"):]: self._z[k].item() for k in self._z.files if k.startswith("attrs_")}
+
+    def __contains__(self, key):
+        return key in self._z.files
+
+    def __getitem__(self, key):
+        return self._z[key]          # ndarray: supports [()] and [index] like an h5py dataset
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self._z.close()
+        return False
+
+
+def open_episode(path):
+    if path.endswith(".npz"):
+        return _NpzEpisode(path)
+    try:
+        import h5py
+    except ImportError as e:                                     # pragma: no cover - h5py is absent in the build container
+        raise RuntimeError(f"{path}: reading HDF5 episodes needs h5py") from e
+    return h5py.File(path, "r")
+
+
+def preprocess_base_action(base_action):
+    """utils.py:312-321 (smoothing of the mobile-base action by a length-5 moving average per column)."""
+    base_action = np.asarray(base_action)
+    return np.stack([np.convolve(base_action[:, i], np.ones(5) / 5, mode="same") for i in range(base_action.shape[1])],
+                    axis=-1).astype(np.float32)
+
+
+def _read_action(root):
+    if "/base_action" in root:
+        return np.concatenate([root["/action"][()], preprocess_base_action(root["/base_action"][()])], axis=-1)
+    return root["/action"][()]
+
+
+def find_all_hdf5(dataset_dir, skip_mirrored_data):
+    files = []
+    for root, _dirs, names in os.walk(dataset_dir):
+        for pat in ("*.hdf5", "*.npz"):
+            for filename in fnmatch.filter(names, pat):
+                if "features" in filename:
+                    continue
+                if skip_mirrored_data and "mirror" in filename:
+                    continue
+                files.append(os.path.join(root, filename))
+    files.sort()                                                 # os.walk order is file-system dependent
+    print(f"Found {len(files)} hdf5 files")
+    return files
+
+
+def get_norm_stats(dataset_path_list):
+    all_qpos, all_action, all_episode_len = [], [], []
+    qpos = None
+    for dataset_path in dataset_path_list:
+        with open_episode(dataset_path) as root:
+            qpos = np.asarray(root["/observations/qpos"][()])
+            action = np.asarray(_read_action(root))
+        all_qpos.append(torch.from_numpy(qpos))
+        all_action.append(torch.from_numpy(action))
+        all_episode_len.append(len(qpos))
+    all_qpos = torch.cat(all_qpos, dim=0)
+    all_action = torch.cat(all_action, dim=0)
+    action_mean = all_action.mean(dim=[0]).float()
+    action_std = torch.clip(all_action.std(dim=[0]).float(), 1e-2, np.inf)
+    qpos_mean = all_qpos.mean(dim=[0]).float()
+    qpos_std = torch.clip(all_qpos.std(dim=[0]).float(), 1e-2, np.inf)
+    action_min = all_action.min(dim=0).values.float()
+    action_max = all_action.max(dim=0).values.float()
+    eps = 0.0001
+    stats = {"action_mean": action_mean.numpy(), "action_std": action_std.numpy(),
+             "action_min": action_min.numpy() - eps, "action_max": action_max.numpy() + eps,
+             "qpos_mean": qpos_mean.numpy(), "qpos_std": qpos_std.numpy(), "example_qpos": qpos}
+    return stats, all_episode_len
+
+
+def BatchSampler(batch_size, episode_len_l, sample_weights, rng=None):
+    """utils.py:237-247; ``rng`` (a ``numpy.random.Generator`` or the ``numpy.random`` module) makes it reproducible."""
+    rng = rng or np.random
+    sample_probs = np.array(sample_weights) / np.sum(sample_weights) if sample_weights is not None else None
+    sum_dataset_len_l = np.cumsum([0] + [np.sum(episode_len) for episode_len in episode_len_l])
+    randint = rng.integers if hasattr(rng, "integers") else rng.randint
+    while True:
+        batch = []
+        for _ in range(batch_size):
+            episode_idx = rng.choice(len(episode_len_l), p=sample_probs)
+            batch.append(int(randint(sum_dataset_len_l[episode_idx], sum_dataset_len_l[episode_idx + 1])))
+        yield batch
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dataset
+# ---------------------------------------------------------------------------------------------------------------------
+class EpisodicDataset(torch.utils.data.Dataset):
+    """utils.py:41-174.  ``__getitem__`` returns (image, qpos, action, is_pad); image is u8 ``[C,H,W,3]`` unless
+    ``f32_images``."""
+
+    def __init__(self, dataset_path_list, camera_names, norm_stats, episode_ids, episode_len, chunk_size, policy_class,
+                 f32_images=False):
+        self.episode_ids = episode_ids
+        self.dataset_path_list = dataset_path_list
+        self.camera_names = camera_names
+        self.norm_stats = norm_stats
+        self.episode_len = episode_len
+        self.chunk_size = chunk_size
+        self.cumulative_len = np.cumsum(self.episode_len)
+        self.max_episode_len = max(episode_len)
+        self.policy_class = policy_class
+        self.f32_images = f32_images
+        if policy_class == "Diffusion":
+            raise NotImplementedError("the Diffusion augmentations (torchvision transforms) are outside this path")
+        self._stats_t = {k: torch.as_tensor(np.asarray(norm_stats[k]), dtype=torch.float32)
+                         for k in ("action_mean", "action_std", "qpos_mean", "qpos_std")}
+        self.is_sim = False          # utils.py:59 (the reference overwrites what __getitem__ observed)
+
+    def __len__(self):
+        return int(self.cumulative_len[-1])
+
+    def _locate_transition(self, index):
+        assert index < self.cumulative_len[-1]
+        episode_index = int(np.argmax(self.cumulative_len > index))       # first True
+        start_ts = int(index - (self.cumulative_len[episode_index] - self.episode_len[episode_index]))
+        return self.episode_ids[episode_index], start_ts
+
+    def __getitem__(self, index):
+        episode_id, start_ts = self._locate_transition(index)
+        dataset_path = self.dataset_path_list[episode_id]
+        with open_episode(dataset_path) as root:
+            attrs = root.attrs
+            is_sim = bool(attrs["sim"]) if "sim" in attrs else False         # legacy data lacks the attribute
+            if attrs.get("compress", False):
+                raise NotImplementedError(f"{dataset_path}: compressed images need cv2.imdecode (absent here)")
+            action = np.asarray(_read_action(root))
+            original_action_shape = action.shape
+            episode_len = original_action_shape[0]
+            qpos = np.asarray(root["/observations/qpos"][start_ts])
+            images = [np.asarray(root[f"/observations/images/{cam}"][start_ts]) for cam in self.camera_names]
+        if is_sim:
+            action = action[start_ts:]
+            action_len = episode_len - start_ts
+        else:                                                     # "hack, to make timesteps more aligned" (utils.py:112-114)
+            action = action[max(0, start_ts - 1):]
+            action_len = episode_len - max(0, start_ts - 1)
+        padded_action = np.zeros((self.max_episode_len, original_action_shape[1]), dtype=np.float32)
+        padded_action[:action_len] = action
+        is_pad = np.zeros(self.max_episode_len)
+        is_pad[action_len:] = 1
+        padded_action = padded_action[:self.chunk_size]
+        is_pad = is_pad[:self.chunk_size]
+        image_data = torch.from_numpy(np.stack(images, axis=0))                # [C,H,W,3] u8
+        qpos_data = torch.from_numpy(qpos).float()
+        action_data = torch.from_numpy(padded_action).float()
+        is_pad = torch.from_numpy(is_pad).bool()
+        if self.f32_images:
+            image_data = torch.einsum("k h w c -> k c h w", image_data) / 255.0
+        t = self._stats_t
+        action_data = (action_data - t["action_mean"]) / t["action_std"]
+        qpos_data = (qpos_data - t["qpos_mean"]) / t["qpos_std"]
+        return image_data, qpos_data, action_data, is_pad
+
+
+def flatten_list(l):
+    return [item for sublist in l for item in sublist]
+
+
+def load_data(dataset_dir_l, name_filter, camera_names, batch_size_train, batch_size_val, chunk_size,
+              skip_mirrored_data=False, load_pretrain=False, policy_class=None, stats_dir_l=None, sample_weights=None,
+              train_ratio=0.99, num_workers=2, f32_images=False, rng=None):
+    """utils.py:249-301.  Returns (train_dataloader, val_dataloader, norm_stats, is_sim)."""
+    rng = rng or np.random
+    if isinstance(dataset_dir_l, str):
+        dataset_dir_l = [dataset_dir_l]
+    dataset_path_list_list = [find_all_hdf5(d, skip_mirrored_data) for d in dataset_dir_l]
+    num_episodes_0 = len(dataset_path_list_list[0])
+    dataset_path_list = [n for n in flatten_list(dataset_path_list_list) if name_filter(n)]
+    num_episodes_l = [len(l) for l in dataset_path_list_list]
+    num_episodes_cumsum = np.cumsum(num_episodes_l)
+    shuffled_episode_ids_0 = rng.permutation(num_episodes_0)
+    train_episode_ids_0 = shuffled_episode_ids_0[:int(train_ratio * num_episodes_0)]
+    val_episode_ids_0 = shuffled_episode_ids_0[int(train_ratio * num_episodes_0):]
+    train_episode_ids_l = [train_episode_ids_0] + [np.arange(n) + num_episodes_cumsum[idx]
+                                                   for idx, n in enumerate(num_episodes_l[1:])]
+    val_episode_ids_l = [val_episode_ids_0]
+    train_episode_ids = np.concatenate(train_episode_ids_l)
+    val_episode_ids = np.concatenate(val_episode_ids_l)
+    print(f"\n\nData from: {dataset_dir_l}\n- Train on {[len(x) for x in train_episode_ids_l]} episodes\n"
+          f"- Test on {[len(x) for x in val_episode_ids_l]} episodes\n\n")
+    _, all_episode_len = get_norm_stats(dataset_path_list)
+    train_episode_len_l = [[all_episode_len[i] for i in ids] for ids in train_episode_ids_l]
+    val_episode_len_l = [[all_episode_len[i] for i in ids] for ids in val_episode_ids_l]
+    train_episode_len = flatten_list(train_episode_len_l)
+    val_episode_len = flatten_list(val_episode_len_l)
+    if stats_dir_l is None:
+        stats_dir_l = dataset_dir_l
+    elif isinstance(stats_dir_l, str):
+        stats_dir_l = [stats_dir_l]
+    norm_stats, _ = get_norm_stats(flatten_list([find_all_hdf5(d, skip_mirrored_data) for d in stats_dir_l]))
+    print(f"Norm stats from: {stats_dir_l}")
+    train_dataset = EpisodicDataset(dataset_path_list, camera_names, norm_stats, train_episode_ids, train_episode_len,
+                                    chunk_size, policy_class, f32_images)
+    val_dataset = EpisodicDataset(dataset_path_list, camera_names, norm_stats, val_episode_ids, val_episode_len,
+                                  chunk_size, policy_class, f32_images)
+    from torch.utils.data import DataLoader
+    kw = dict(pin_memory=torch.cuda.is_available(), num_workers=num_workers)
+    if num_workers > 0:
+        kw["prefetch_factor"] = 2
+    train_dataloader = DataLoader(train_dataset, batch_sampler=BatchSampler(batch_size_train, train_episode_len_l,
+                                                                             sample_weights, rng), **kw)
+    val_dataloader = DataLoader(val_dataset, batch_sampler=BatchSampler(batch_size_val, val_episode_len_l, None, rng), **kw)
+    return train_dataloader, val_dataloader, norm_stats, train_dataset.is_sim
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# host -> device hand-off
+# ---------------------------------------------------------------------------------------------------------------------
+class DevicePrefetcher:
+    """Wraps an iterable of host batches (tuples of tensors): batch i+1 is copied to the device on a side stream
+    (from pinned memory, ``non_blocking``) while the caller computes on batch i; ``__next__`` makes the compute stream
+    wait for the copy it is about to use.  On a CPU-only host it degrades to the plain iterable (tests)."""
+
+    def __init__(self, iterable, device=None, depth=2):
+        self.it = iter(iterable)
+        self.device = torch.device(device) if device is not None else (
+            torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None)
+        self.cuda = self.device is not None and self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self.queue = []
+        self.depth = max(1, int(depth))
+        for _ in range(self.depth):
+            self._push()
+
+    def _push(self):
+        try:
+            batch = next(self.it)
+        except StopIteration:
+            return
+        if not self.cuda:
+            self.queue.append((batch, None))
+            return
+        with torch.cuda.stream(self.stream):
+            staged = tuple(t if t.is_pinned() else t.pin_memory() for t in batch)
+            dev = tuple(t.to(self.device, non_blocking=True) for t in staged)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.queue.append((dev, ev))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if not self.queue:
+            raise StopIteration
+        batch, ev = self.queue.pop(0)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            for t in batch:
+                t.record_stream(torch.cuda.current_stream(self.device))
+        self._push()
+        return batch

@@ -256,7 +256,8 @@ def train_bc(train_dataloader, val_dataloader, config, log=None):
     min_val_loss = np.inf
     best_ckpt_info = None
     os.makedirs(ckpt_dir, exist_ok=True)
-    train_dataloader = repeater(train_dataloader)
+    from actmi.data import DevicePrefetcher
+    train_dataloader = DevicePrefetcher(repeater(train_dataloader))      # next batch's H2D copy overlaps this step
     for step in range(num_steps + 1):
         if step % validate_every == 0:
             policy.eval()
@@ -338,10 +339,25 @@ def main(args):
     from actmi.config import ACTConfig
     from actmi.envs import SyntheticDataset
     cfg = ACTConfig.from_policy_config(config["policy_config"])
-    train_dl = SyntheticDataset(cfg, args["batch_size"], 8, seed=args["seed"])
-    val_dl = SyntheticDataset(cfg, args["batch_size"], 2, seed=args["seed"] + 1)
+    task_config = SIM_TASK_CONFIGS[args["task_name"]]
+    camera_names, policy_class = config["camera_names"], config["policy_class"]
+    dataset_dir = args.get("dataset_dir") or task_config.get("dataset_dir")
+    if dataset_dir and os.path.isdir(dataset_dir):
+        # reference imitate_episodes.py:141-147: episodes on disk (HDF5 via h5py, or .npz with the same keys), z-scored
+        # qpos / actions, u8 images; batches reach the device through pinned staging on a side stream
+        from actmi.data import load_data
+        name_filter = task_config.get("name_filter", lambda n: True)
+        train_dl, val_dl, stats, _ = load_data(dataset_dir, name_filter, camera_names, args["batch_size"], args["batch_size"],
+                                               args.get("chunk_size") or 100, args.get("skip_mirrored_data", False),
+                                               policy_class=policy_class, stats_dir_l=task_config.get("stats_dir"),
+                                               sample_weights=task_config.get("sample_weights"),
+                                               train_ratio=task_config.get("train_ratio", 0.99))
+    else:
+        train_dl = SyntheticDataset(cfg, args["batch_size"], 8, seed=args["seed"])
+        val_dl = SyntheticDataset(cfg, args["batch_size"], 2, seed=args["seed"] + 1)
+        stats = _default_stats(14)
     with open(os.path.join(config["ckpt_dir"], "dataset_stats.pkl"), "wb") as f:
-        pickle.dump(_default_stats(14), f)
+        pickle.dump(stats, f)
     best_step, min_val_loss, best_state_dict = train_bc(train_dl, val_dl, config)
     torch.save(best_state_dict, os.path.join(config["ckpt_dir"], "policy_best.ckpt"))
     print(f"Best ckpt, val loss {min_val_loss:.6f} @ step{best_step}")
@@ -376,4 +392,6 @@ if __name__ == "__main__":
     # additions (rollouts count hard-coded to 10 in the reference, :156)
     parser.add_argument("--num_rollouts", action="store", type=int, default=50)
     parser.add_argument("--max_batch", action="store", type=int, default=None)
+    parser.add_argument("--dataset_dir", action="store", type=str, default=None,
+                        help="episode files (reference HDF5 layout, or .npz with the same keys); default: the task's dataset_dir")
     main(vars(parser.parse_args()))

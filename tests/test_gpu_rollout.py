@@ -57,3 +57,34 @@ def test_batched_rollout_matches_sequential_oracle(tmp_path):
             ts = env.step(raw[:-2])
     print(f"rollout: max|raw_action - sequential oracle| = {worst:.3e}")
     assert worst <= 1e-4
+
+
+def test_training_loop_on_episode_files(tmp_path):
+    """imitate_episodes.main (training branch) over episode files in the reference's key layout: load_data ->
+    pinned staging -> DevicePrefetcher -> forward/backward/AdamW; checkpoints and dataset_stats.pkl are written."""
+    import os
+    import pickle
+    rng = np.random.default_rng(0)
+    data = tmp_path / "data"
+    data.mkdir()
+    cams = ["top", "left_wrist", "right_wrist"]                    # sim_transfer_cube_scripted (constants.py)
+    for i in range(4):
+        T = 5 + i
+        ep = {"/observations/qpos": rng.standard_normal((T, 14)).astype(np.float32),
+              "/observations/qvel": rng.standard_normal((T, 14)).astype(np.float32),
+              "/action": rng.standard_normal((T, 16)).astype(np.float32), "attrs_sim": np.array(True)}
+        for c in cams:
+            ep[f"/observations/images/{c}"] = rng.integers(0, 256, (T, 480, 640, 3), dtype=np.uint8)
+        np.savez(data / f"episode_{i}.npz", **ep)
+    ck = tmp_path / "ck"
+    args = dict(eval=False, ckpt_dir=str(ck), policy_class="ACT", task_name="sim_transfer_cube_scripted", batch_size=2,
+                seed=0, num_steps=2, lr=1e-5, kl_weight=10, chunk_size=100, hidden_dim=512, dim_feedforward=3200,
+                temporal_agg=False, eval_every=1000, validate_every=2, save_every=1000, dataset_dir=str(data),
+                num_rollouts=1, max_batch=2)
+    IE.main(args)
+    assert os.path.isfile(ck / "policy_last.ckpt") and os.path.isfile(ck / "policy_best.ckpt")
+    with open(ck / "dataset_stats.pkl", "rb") as f:
+        stats = pickle.load(f)                       # written by this program a moment ago
+    assert stats["action_mean"].shape == (16,) and stats["qpos_std"].shape == (14,)
+    sd = torch.load(ck / "policy_last.ckpt", weights_only=True)
+    assert all(torch.isfinite(v).all() for v in sd.values())
