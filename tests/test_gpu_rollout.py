@@ -59,6 +59,7 @@ def test_batched_rollout_matches_sequential_oracle(tmp_path):
     assert worst <= 1e-4
 
 
+@pytest.mark.filterwarnings("ignore::DeprecationWarning")        # torch's own pin_memory helper
 def test_training_loop_on_episode_files(tmp_path):
     """imitate_episodes.main (training branch) over episode files in the reference's key layout: load_data ->
     pinned staging -> DevicePrefetcher -> forward/backward/AdamW; checkpoints and dataset_stats.pkl are written."""
