@@ -63,7 +63,8 @@ __device__ __forceinline__ int swz_row(int r) { return r ^ ((r >> 3) & 3); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC, int BSPLIT>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128 * 64 && (AMODE == 0 /*A_N*/ || AMODE == 3 /*A_T*/) && !(AMODE == 0 && BMODE == 1)) ? 3 : 2)
+    void gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;      // 256 threads (4 waves) or 512 (8 waves, 2 per SIMD) for the 256x128 tile
     constexpr int RPP = NT / 8;                          // rows staged per pass of the N-form loaders
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -910,7 +911,9 @@ int launch_modes(const GemmArgs& a, hipStream_t st) {
     const int nzs = nz * (a.splitk > 1 ? a.splitk : 1);
     const double fixed = PREC ? 10.0 : 2.5;
     const double cL = tile_cost(a.M, a.N, Ks, nzs, 128, 128, 1.00, fixed);
-    const double cM = tile_cost(a.M, a.N, Ks, nzs, 128, 64, PREC ? 0.74 : 0.95, fixed);
+    // f16x3 128x64: the plain row-major and the transposed-A forms fit 168 VGPRs -> three waves per SIMD (0.74 -> 0.83 of
+    // the 128x128 rate); the gather forms spill at that budget and stay at two
+    const double cM = tile_cost(a.M, a.N, Ks, nzs, 128, 64, PREC ? ((AMODE == A_N || AMODE == A_T) ? 0.83 : 0.74) : 0.95, fixed);
     const double cS = tile_cost(a.M, a.N, Ks, nzs, 64, 64, PREC ? 0.68 : 0.88, fixed);
     double eL = -cL, eM = -cM, eS = -cS;
     if (!PREC) {
