@@ -117,6 +117,26 @@ def test_batch_independence_and_determinism():
     assert torch.isfinite(a8).all()
 
 
+def test_f16x3_agrees_with_native_fp32_at_benchmark_size():
+    """The benchmark configuration (C=4, 480x640, B=8) has no golden fixture (the oracle takes minutes there): pin the
+    default arithmetic (fp32 products from three fp16 MFMA products) against the native fp32 MFMA path on the same
+    weights and inputs -- the same bound as run-to-run summation-order noise of the fp32 path itself."""
+    from actmi.config import ACTConfig
+    cfg = ACTConfig()
+    sd_np = W.generate_state_dict(cfg, seed=0)
+    inp = W.generate_inputs(cfg, 8, seed=6)
+    q = torch.from_numpy(inp["qpos"]).cuda()
+    im = torch.from_numpy(inp["image_u8"]).cuda()
+    outs = {}
+    for prec in ("f16x3", "f32"):
+        eng = _engine(cfg, sd_np, 8, prec)
+        outs[prec] = eng.forward_infer(q, im).clone()
+        del eng
+    d = float((outs["f16x3"] - outs["f32"]).abs().max())
+    print(f"benchmark size: max|a_hat(f16x3) - a_hat(f32)| = {d:.3e}, |a_hat| max {float(outs['f32'].abs().max()):.3f}")
+    assert d <= 3e-5
+
+
 def test_state_dict_round_trip_and_errors():
     from actmi.config import tiny_config
     cfg = tiny_config()
