@@ -99,6 +99,22 @@ def test_forward_batch_sizes_against_oracle():
         assert np.abs(got - exp).max() <= ATOL
 
 
+@pytest.mark.parametrize("cams,h,w", [(["only"], 64, 64), (["a", "b", "c", "d", "e"], 64, 96)])
+def test_forward_other_camera_counts(cams, h, w):
+    """one camera and five cameras (the fixtures cover 2, 3 and 4): token layout 2 + C*fh*fw, per-camera weights"""
+    from oracle import act_ref as R
+    from actmi.config import tiny_config
+    cfg = tiny_config(camera_names=cams, image_h=h, image_w=w)
+    sd_np = W.generate_state_dict(cfg, seed=21)
+    eng = _engine(cfg, sd_np, 2)
+    inp = W.generate_inputs(cfg, 2, seed=8)
+    with torch.no_grad():
+        exp = R.policy_call(torch_sd(sd_np), cfg, torch.from_numpy(inp["qpos"]),
+                            torch.from_numpy(W.u8_nhwc_to_f32_nchw(inp["image_u8"]))).numpy()
+    got = eng.forward_infer(torch.from_numpy(inp["qpos"]).cuda(), torch.from_numpy(inp["image_u8"]).cuda()).cpu().numpy()
+    assert np.abs(got - exp).max() <= ATOL
+
+
 def test_batch_independence_and_determinism():
     """Size-independent properties at the benchmark configuration (C=4, 480x640, B=8): a sample's output does not
     depend on its batch neighbours (FrozenBN => no batch statistics) and repeated runs are bit-identical."""
