@@ -179,7 +179,8 @@ class ACTEngine:
         if with_ensemble is not None:
             with_ensemble.reset()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: calls made by other threads (e.g. the RCCL watchdog of a multi-rank bench) must not void the capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             self.forward_infer(s_qpos, s_img, out=s_out)
             ens_out = with_ensemble.step(s_out) if with_ensemble is not None else None
         if with_ensemble is not None:
