@@ -43,6 +43,7 @@ class GemmDesc(C.Structure):
         ("gA2", C.c_int64), ("gB2", C.c_int64), ("gC2", C.c_int64), ("gRes2", C.c_int64),
         ("gMask", C.c_int64), ("gC2out", C.c_int64),
         ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("stamps", C.c_void_p), ("prec", C.c_int32), ("b_split", C.c_int32), ("b_scale", C.c_float), ("a_scale", C.c_float), ("a_scale_dev", C.c_void_p), ("b_scale_dev", C.c_void_p),
+        ("split_stride", C.c_int64),
     ]
 
 
@@ -96,6 +97,7 @@ def load():
         "actmi_op_split16": ([vp, vp, C.c_int64, C.c_float, vp], i32),
         "actmi_op_sample_onehot": ([vp, i32, i32, C.c_float, C.c_uint64, vp, vp, vp], i32),
         "actmi_op_pow2_scale": ([vp, C.c_int64, i32, i32, vp, vp], i32),
+        "actmi_op_splitk_combine": ([vp, i32, C.c_int64, C.c_int64, i32, i32, vp, vp, vp, C.c_int64, i32, vp, C.c_int64, vp], i32),
         "actmi_op_attention": ([C.POINTER(AttnDesc), vp], i32),
         "actmi_op_layernorm": ([vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp], i32),
         "actmi_op_maxpool3x3s2": ([vp, vp, i32, i32, i32, i32, vp], i32),

@@ -36,11 +36,34 @@ def pow2_scale(x):
 
 def gemm(A, W, bias=None, scale=None, res=None, res_mod=0, relu=False, a_add=None, add_mod=0, add_ncols=0, rowmap=None,
          out=None, out_rows=None, drop_p=0.0, drop_seed=0, prec=None, w_split=False, a_scale=0.0, b_scale=0.0,
-         a_scale_dev=None, b_scale_dev=None):
-    """out[rowmap(m)] = act((A' @ W.T) * scale + bias + res[m % res_mod]); A [M,K], W [N,K] row-major f32 cuda."""
+         a_scale_dev=None, b_scale_dev=None, splitk=0):
+    """out[rowmap(m)] = act((A' @ W.T) * scale + bias + res[m % res_mod]); A [M,K], W [N,K] row-major f32 cuda.
+    splitk > 1: the contraction is split into that many plain slices which a combine pass sums in a fixed order before
+    the epilogue (what the engine does for small grids); no rowmap / res_mod / dropout in that form."""
     lib = L.load()
     M, K = A.shape
     N = W.shape[0]
+    if splitk and splitk > 1:
+        assert rowmap is None and not res_mod and not drop_p
+        part = torch.empty((splitk, M, N), dtype=torch.float32, device=A.device)
+        d = L.GemmDesc()
+        d.A, d.lda, d.mode = A.data_ptr(), A.stride(0), 0
+        if a_add is not None:
+            d.A_add, d.ld_add, d.add_mod, d.add_ncols = a_add.data_ptr(), a_add.stride(0), add_mod, add_ncols
+        d.Bw, d.ldb = W.data_ptr(), W.stride(0)
+        d.C, d.ldc = part.data_ptr(), N
+        d.M, d.N, d.K, d.groups = M, N, K, 1
+        d.splitk, d.split_stride = int(splitk), M * N
+        d.prec, d.b_split, d.b_scale = PREC[prec], 1 if w_split else 0, float(w_split) if w_split else float(b_scale)
+        d.a_scale = float(a_scale)
+        L.check(lib.actmi_op_gemm(C.byref(d), L.current_stream_ptr()), None, "op_gemm")
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+        L.check(lib.actmi_op_splitk_combine(part.data_ptr(), int(splitk), M * N, N, M, N, _p(scale), _p(bias), _p(res),
+                                            res.stride(0) if res is not None else 0,
+                                            2 if relu == "gelu" else (1 if relu else 0), out.data_ptr(), out.stride(0),
+                                            L.current_stream_ptr()), None, "op_splitk_combine")
+        return out
     if out is None:
         out = torch.zeros((out_rows or M, N), dtype=torch.float32, device=A.device)
     d = L.GemmDesc()

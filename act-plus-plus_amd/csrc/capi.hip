@@ -139,6 +139,20 @@ int actmi_op_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, vo
     return launch_pow2_scale(x, ld, M, N, out, S(stream)) == 0 ? 0 : ACTMI_E_LAUNCH;
 }
 
+int actmi_op_splitk_combine(const float* part, int nsplit, int64_t split_stride, int64_t ldp, int M, int N, const float* scale,
+                            const float* bias, const float* res, int64_t ldres, int relu, float* out, int64_t ldc, void* stream) {
+    g_op_error.clear();
+    if (!part || !out || nsplit < 1 || M < 0 || N < 0 || ldp < N || ldc < N || (res && ldres < N) || relu < 0 || relu > 2) {
+        g_op_error = "splitk_combine: bad argument";
+        return ACTMI_E_INVALID;
+    }
+    SplitCombineArgs c{};
+    c.part = part; c.nsplit = nsplit; c.split_stride = split_stride; c.ldp = ldp;
+    c.scale = scale; c.bias = bias; c.res = res; c.ldres = ldres; c.relu = relu;
+    c.C = out; c.ldc = ldc; c.M = M; c.N = N; c.groups = 1;
+    return launch_splitk_combine(c, S(stream)) == 0 ? 0 : ACTMI_E_LAUNCH;
+}
+
 int actmi_op_sample_onehot(const float* logits, int n, int V, float temperature, uint64_t seed, float* probs, float* code,
                            void* stream) {
     g_op_error.clear();

@@ -21,6 +21,24 @@ typedef actmi_gemm_desc GemmArgs;
 
 int launch_gemm(const GemmArgs& a, hipStream_t st, std::string* err);
 
+// sums the slices of a sliced split-K product (GemmArgs::split_stride) in split order and applies the forward epilogue
+// v = sum * scale[n] + bias[n] (+ res[m][n]) -> ReLU / GELU (misc.hip)
+struct SplitCombineArgs {
+    const float* part;        // slice s of group g: part + g*gP + s*split_stride, rows of ldp floats
+    int nsplit;
+    int64_t split_stride, gP, ldp;
+    const float* scale;       // per-n or NULL (group stride gSB)
+    const float* bias;
+    int64_t gSB;
+    const float* res;         // optional [M][ldres] (group stride gRes)
+    int64_t ldres, gRes;
+    int relu;                 // 0 none, 1 ReLU, 2 GELU
+    float* C;
+    int64_t ldc, gC;
+    int M, N, groups;
+};
+int launch_splitk_combine(const SplitCombineArgs& a, hipStream_t st);
+
 // ---- conv1 7x7/s2 + FrozenBN + ReLU (conv1.hip) -----------------------------------------------
 struct Conv1Args {
     const void* image;    // u8 NHWC [B][C][H][W][3] or f32 NCHW [B][C][3][H][W]

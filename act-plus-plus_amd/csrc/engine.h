@@ -87,6 +87,10 @@ struct actmi_ctx {
     float* pbase = nullptr;
     float* p16base = nullptr;          // fp16-split image of the parameter arena (B operands of the f16x3 GEMM)
     int gemm_prec = 0;                 // ACTMI_PREC_* used by the forward GEMMs of this handle
+    float* splitk_ws = nullptr;        // slices of the forward GEMMs whose contraction is split to fill the chip
+    int64_t splitk_ws_floats = 0;
+    int fwd_splitk = 1;                // 0: never split a forward contraction (ACTMI_FWD_SPLITK=0)
+    int sk_target = 1536, sk_minnk = 12, sk_maxtiles = 768;     // split heuristic (tuning aids ACTMI_FWD_SPLITK_*)
     int64_t ptotal = 0;
     bool finalized = false;
     // geometry

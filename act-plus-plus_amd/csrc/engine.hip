@@ -166,6 +166,43 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
                 if (a.Bw == cl.w) { a.Bw = cl.w16; a.b_split = 1; a.b_scale = W16_SCALE; break; }
         }
     }
+    // Small grids (B = 1-4 rollouts: layer3/4 convolutions, the K = 3200 FFN products): a launch of a few hundred tiles
+    // leaves CUs idle and its lone workgroups latency-bound on a long K loop.  Split the contraction over blockIdx.z into
+    // plain slices and let a combine pass sum them in a fixed order and apply the epilogue.  Thresholds from a sweep at
+    // B = 1, 2, 4, 8 (tools/splitk_sweep.sh): aim at 1536 64x64-tile equivalents, keep >= 12 K tiles per split, leave
+    // launches of >= 768 such tiles alone (B = 8 and the training batch never qualify).
+    if (ctx->fwd_splitk && ctx->splitk_ws && a.splitk <= 1 && a.tb == 0 && a.ta == 0 && (a.mode == 0 || a.mode == 1) &&
+        !a.rowmap && !a.C2 && !a.mask && a.drop_p == 0.f && a.res_mod == 0 && a.groups_inner == 0 && !a.stamps) {
+        const int groups = a.groups > 0 ? a.groups : 1;
+        const int64_t tiles = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64) * groups;
+        const int nk = (a.K + 31) / 32;
+        int S = tiles < ctx->sk_maxtiles ? (int)((ctx->sk_target + tiles - 1) / tiles) : 1;
+        if (S > 8) S = 8;
+        if (S > nk / ctx->sk_minnk) S = nk / ctx->sk_minnk;
+        const int64_t slice = (int64_t)a.M * a.N;
+        if (S >= 2 && slice * groups * S <= ctx->splitk_ws_floats && (a.N & 3) == 0) {
+            GemmArgs p = a;
+            p.scale = p.bias = p.res = nullptr;
+            p.relu = 0;
+            p.C = ctx->splitk_ws;
+            p.ldc = a.N;
+            p.gC = slice * S;
+            p.splitk = S;
+            p.split_stride = slice;
+            int rc = launch_gemm(p, st, &ctx->err);
+            if (rc) return rc;
+            SplitCombineArgs c{};
+            c.part = ctx->splitk_ws; c.nsplit = S; c.split_stride = slice; c.gP = slice * S; c.ldp = a.N;
+            c.scale = a.scale; c.bias = a.bias; c.gSB = a.gSB;
+            c.res = a.res; c.ldres = a.ldres; c.gRes = a.gRes;
+            c.relu = a.relu;
+            c.C = a.C; c.ldc = a.ldc; c.gC = a.gC;
+            c.M = a.M; c.N = a.N; c.groups = groups;
+            rc = launch_splitk_combine(c, st);
+            if (rc) ctx->err = "splitk combine launch failed";
+            return rc;
+        }
+    }
     return launch_gemm(a, st, &ctx->err);
 }
 
@@ -268,6 +305,13 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
         ctx->gemm_prec = (e && e[0] == 'f' && e[1] == '3') ? ACTMI_PREC_F32 : ACTMI_PREC_F16X3;
         if (ctx->ptotal & 3) { ctx->err = "parameter arena not a multiple of 4 floats"; return fail(ACTMI_E_LAUNCH); }
         if ((rc = dev_alloc(ctx, &ctx->p16base, ctx->ptotal))) return fail(rc);
+        const char* sk = getenv("ACTMI_FWD_SPLITK");
+        ctx->fwd_splitk = !(sk && sk[0] == '0');
+        if (const char* e2 = getenv("ACTMI_FWD_SPLITK_TARGET")) ctx->sk_target = atoi(e2);
+        if (const char* e2 = getenv("ACTMI_FWD_SPLITK_MINNK")) ctx->sk_minnk = atoi(e2) > 0 ? atoi(e2) : 1;
+        if (const char* e2 = getenv("ACTMI_FWD_SPLITK_MAXTILES")) ctx->sk_maxtiles = atoi(e2);
+        ctx->splitk_ws_floats = (int64_t)16 << 20;          // 64 MB: small-batch slices only (ctx_gemm checks the fit)
+        if ((rc = dev_alloc(ctx, &ctx->splitk_ws, ctx->splitk_ws_floats))) return fail(rc);
     }
     resolve_layers(ctx);
 

@@ -685,7 +685,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
     const float* res = p.res ? p.res + offRes : nullptr;
     const float* mask = p.mask ? p.mask + (int64_t)g * p.gMask : nullptr;
     const int64_t ldmask = p.ldmask ? p.ldmask : p.ldc;
-    float* C = p.C + offC;
+    float* C = p.C + offC + (int64_t)split * p.split_stride;      // split_stride != 0: one plain slice per split
     float* C2 = p.C2 ? p.C2 + (int64_t)g * p.gC2out : nullptr;
     // a pre-split B image may carry a power-of-two scale (keeps small weights' lo pieces out of fp16 subnormals)
     float alpha = p.alpha != 0.f ? p.alpha : 1.f;
@@ -700,7 +700,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
     // Fast epilogue for the forward-pass cases (bias / FrozenBN affine, optional same-shape residual, optional ReLU): the
     // feature-complete path below costs ~140 instructions per element (per-element branches, 64-bit index arithmetic) and
     // was measured at 45-75k cycles per 128x128 tile, a quarter of a K=512 main loop; this one is a few thousand.
-    const bool simple = !has_map && splitk <= 1 && !C2 && !(p.drop_p > 0.f) && p.res_mod == 0 &&
+    const bool simple = !has_map && (splitk <= 1 || p.split_stride != 0) && !C2 && !(p.drop_p > 0.f) && p.res_mod == 0 &&
                         (!has_mask || (int64_t)p.M * ldmask < (int64_t)1 << 31) &&
                         (int64_t)p.M * p.ldc < (int64_t)1 << 31 && (!has_res || (int64_t)p.M * p.ldres < (int64_t)1 << 31);
     if (simple) {
@@ -837,7 +837,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                     v += rv[e];
                     if (!(mv[e] > 0.f)) v = 0.f;
                     if (p.relu) v = fmaxf(v, 0.f);
-                    if (splitk > 1) atomicAdd(&C[o], v);
+                    if (splitk > 1 && p.split_stride == 0) atomicAdd(&C[o], v);
                     else C[o] = v;
                     if (C2) C2[o] = v * sc2;
                 }
@@ -944,6 +944,11 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t st, std::string* err) {
     if (a.K <= 0) return fail("K must be positive");
     if (((uintptr_t)a.A & 15) || ((uintptr_t)a.Bw & 15)) return fail("A/B must be 16-byte aligned");
     if (a.splitk > 1 && (a.bias || a.res || a.mask || a.relu || a.C2 || a.scale)) return fail("split-K supports a plain accumulate only");
+    if (a.split_stride != 0) {
+        if (a.splitk <= 1) return fail("split_stride needs splitk > 1");
+        const int nk = (a.K + BK - 1) / BK, tps = (nk + a.splitk - 1) / a.splitk;
+        if ((a.splitk - 1) * tps >= nk) return fail("split_stride: every split must own at least one K tile");
+    }
     if (a.relu == 2 && (a.rowmap || a.C2 || a.drop_p > 0.f || a.res_mod != 0)) return fail("GELU is only available in the plain epilogue");
     if (a.relu < 0 || a.relu > 2) return fail("bad activation");
     if (a.C2 && !a.scale2) return fail("C2 needs scale2");

@@ -285,6 +285,56 @@ int launch_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, hipS
     return (int)hipGetLastError();
 }
 
+namespace {
+template <int V>
+__global__ __launch_bounds__(256) void splitk_combine_kernel(SplitCombineArgs a) {
+    const int nv = a.N / V;
+    const int64_t per_group = (int64_t)a.M * nv;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_group * a.groups) return;
+    const int g = (int)(i / per_group);
+    const int64_t r = i - (int64_t)g * per_group;
+    const int m = (int)(r / nv), n = (int)(r - (int64_t)m * nv) * V;
+    const float* src = a.part + g * a.gP + (int64_t)m * a.ldp + n;
+    float v[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = 0.f;
+    for (int s = 0; s < a.nsplit; ++s) {             // fixed order: run-to-run identical results
+        if (V == 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(src + s * a.split_stride);
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] += t[e];
+        } else v[0] += src[s * a.split_stride];
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const float sc = a.scale ? a.scale[g * a.gSB + n + e] : 1.f;
+        const float bi = a.bias ? a.bias[g * a.gSB + n + e] : 0.f;
+        float x = v[e] * sc + bi;
+        if (a.res) x += a.res[g * a.gRes + (int64_t)m * a.ldres + n + e];
+        if (a.relu == 1) x = fmaxf(x, 0.f);
+        else if (a.relu == 2) x = 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+        v[e] = x;
+    }
+    float* dst = a.C + g * a.gC + (int64_t)m * a.ldc + n;
+    if (V == 4) *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    else dst[0] = v[0];
+}
+}  // namespace
+
+int launch_splitk_combine(const SplitCombineArgs& a, hipStream_t st) {
+    if (a.M <= 0 || a.N <= 0 || a.groups <= 0) return 0;
+    const bool v4 = (a.N & 3) == 0 && (a.ldp & 3) == 0 && (a.ldc & 3) == 0 && (a.split_stride & 3) == 0 && (a.gP & 3) == 0 &&
+                    (a.gC & 3) == 0 && ((uintptr_t)a.part & 15) == 0 && ((uintptr_t)a.C & 15) == 0;
+    const int64_t total = (int64_t)a.groups * a.M * (v4 ? a.N / 4 : a.N);
+    if (prof_enabled())
+        prof_begin("splitk_combine_kernel", 0.0, 4.0 * a.groups * (double)a.M * a.N * (a.nsplit + 1 + (a.res ? 1 : 0)), st);
+    if (v4) hipLaunchKernelGGL(splitk_combine_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(splitk_combine_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    prof_end(st);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 int launch_scale(float* x, int64_t n, float s, hipStream_t st) {
     if (n <= 0) return 0;
     const int64_t n4 = n / 4;

@@ -128,6 +128,10 @@ typedef struct actmi_gemm_desc {
      * with a_scale / b_scale; read by the kernel, so they can be produced on the same stream just before the launch */
     const float* a_scale_dev;
     const float* b_scale_dev;
+    /* splitk > 1 with split_stride != 0: split s stores its partial product plainly at C + s*split_stride (elements; no
+     * atomics, C need not be zeroed, the fast epilogue applies); actmi_op_splitk_combine sums the slices in a fixed order
+     * and applies scale / bias / residual / activation.  Every split must own at least one K tile of 32. */
+    int64_t split_stride;
 } actmi_gemm_desc;
 
 /* Multi-head attention descriptor: softmax(scale * q k^T [+ key padding mask]) v per (batch, head).
@@ -212,6 +216,11 @@ int actmi_op_split16(const float* src, float* dst, int64_t nfloats, float scale,
 /* out[0] = the power of two s with max|x| * s in [2^13, 2^14) over the M x N matrix x (row stride ld); 1 if x is all
  * zero or not finite.  out[1] is scratch and must be zero before the first use (the op leaves it zero).  For actmi_gemm_desc.a_scale_dev / b_scale_dev. */
 int actmi_op_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, void* stream);
+/* second half of a sliced split-K product (actmi_gemm_desc.split_stride): out[m][n] = act((sum_s part[s*split_stride +
+ * m*ldp + n]) * scale[n] + bias[n] + res[m][n]); slices are summed in index order, so results are run-to-run identical.
+ * relu as in actmi_gemm_desc; scale / bias / res may be NULL. */
+int actmi_op_splitk_combine(const float* part, int nsplit, int64_t split_stride, int64_t ldp, int M, int N, const float* scale,
+                            const float* bias, const float* res, int64_t ldres, int relu, float* out, int64_t ldc, void* stream);
 /* one categorical draw per row: code[i] = one_hot(sample(softmax(logits[i] / temperature))) by inverse CDF on the
  * counter-based generator (replaces torch.multinomial in detr_vae.py:140 and latent_model.py:68-69); probs may be NULL */
 int actmi_op_sample_onehot(const float* logits, int n, int V, float temperature, uint64_t seed, float* probs, float* code,

@@ -153,6 +153,29 @@ def test_f16x3_agrees_with_native_fp32_at_benchmark_size():
     assert d <= 3e-5
 
 
+def test_single_query_split_contraction_matches_unsplit(monkeypatch):
+    """B = 1 (the reference's own rollout batch, imitate_episodes.py:390-399): layer3/4 convolutions and the K = 3200
+    FFN products run with their contraction split over the grid + a fixed-order combine pass; the result agrees with the
+    unsplit launches (ACTMI_FWD_SPLITK=0) to summation-order noise and is bitwise repeatable."""
+    from actmi.config import ACTConfig
+    cfg = ACTConfig()
+    sd_np = W.generate_state_dict(cfg, seed=0)
+    inp = W.generate_inputs(cfg, 1, seed=9)
+    q = torch.from_numpy(inp["qpos"]).cuda()
+    im = torch.from_numpy(inp["image_u8"]).cuda()
+    eng = _engine(cfg, sd_np, 1, "f16x3")
+    a = eng.forward_infer(q, im).clone()
+    b = eng.forward_infer(q, im).clone()
+    assert torch.equal(a, b)
+    del eng
+    monkeypatch.setenv("ACTMI_FWD_SPLITK", "0")
+    eng = _engine(cfg, sd_np, 1, "f16x3")
+    c = eng.forward_infer(q, im).clone()
+    d = float((a - c).abs().max())
+    print(f"B=1: max|a_hat(split) - a_hat(unsplit)| = {d:.3e}")
+    assert 0.0 < d <= 3e-5                    # > 0: the split path did run
+
+
 def test_state_dict_round_trip_and_errors():
     from actmi.config import tiny_config
     cfg = tiny_config()

@@ -43,6 +43,32 @@ def test_gemm_shapes(M, N, K, prec):
         assert torch.equal(got, got2)
 
 
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("M,N,K,S,relu", [(100, 512, 3200, 8, False), (300, 192, 1024, 4, True), (77, 64, 2048, 3, "gelu")])
+def test_gemm_sliced_splitk(M, N, K, S, relu, prec):
+    """small-grid form used by the engine at B = 1-2: the contraction split into plain slices + a fixed-order combine
+    pass that carries the epilogue (scale, bias, residual, activation); agrees with the one-pass product and with fp64"""
+    g = torch.Generator().manual_seed(M + K)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+    b, sc, res = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5, torch.randn(M, N, generator=g)
+    d = dev()
+    kw = dict(bias=b.to(d), scale=sc.to(d), res=res.to(d), relu=relu, prec=prec)
+    one = ops.gemm(A.to(d), W.to(d), **kw)
+    two = ops.gemm(A.to(d), W.to(d), splitk=S, **kw)
+    again = ops.gemm(A.to(d), W.to(d), splitk=S, **kw)
+    assert torch.equal(two, again)                                   # no atomics: bitwise repeatable
+    exp = F.linear(A.double(), W.double()) * sc.double() + b.double() + res.double()
+    exp = F.relu(exp) if relu is True else (F.gelu(exp) if relu == "gelu" else exp)
+    assert rel_err(two, exp) < 2e-6 and rel_err(one, exp) < 2e-6
+    assert (two.cpu() - one.cpu()).abs().max() < 1e-5
+
+
+def test_gemm_sliced_splitk_rejects_empty_splits():
+    A, W = torch.randn(64, 64).to(dev()), torch.randn(64, 64).to(dev())
+    with pytest.raises(RuntimeError, match="K tile"):
+        ops.gemm(A, W, splitk=4)                                     # 2 K tiles of 32 cannot feed 4 splits
+
+
 def test_split16_is_an_exact_two_piece_split():
     """hi = rn16(x), lo = rn16(x - hi): hi + lo reproduces x to 2^-22 relative; tiny values survive as fp16
     subnormals (absolute error floor 2^-25); the split image keeps the fp32 matrix's addressing (4 hi halfs + 4 lo halfs
