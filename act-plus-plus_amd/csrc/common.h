@@ -50,7 +50,10 @@ struct Conv1Args {
     float* out;           // camera-major NHWC [C][B][Ho][Wo][Cout]
     int B, C, H, W, Ho, Wo, Cout;
     int prec = 0;         // ACTMI_PREC_* (0 = environment / native fp32)
+    const unsigned char* wimg = nullptr;   // f16x3 only, optional: launch_conv1_wimg's image of w (C x conv1_wimg_bytes())
 };
+int64_t conv1_wimg_bytes();
+int launch_conv1_wimg(const float* w, void* img, int C, int Cout, hipStream_t st);
 int launch_conv1(const Conv1Args& a, hipStream_t st, std::string* err);
 
 // ---- direct 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels, f16x3 (conv3.hip) ----------

@@ -248,6 +248,31 @@ __device__ __forceinline__ uint32_t split1(float v) {              // (hi | lo <
     return (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
 }
 
+// one entry of the weight image: element e = (n, group gi = r*3+g, j) -> (hi, lo) halfs of w[n][r*21 + 8g + j] * 2^8
+__device__ __forceinline__ void conv1_wimg_entry(const float* wg, int Cout, int e, uint16_t& h, uint16_t& l) {
+    const int n = e / (F_NG * 8), rem = e - n * (F_NG * 8);
+    const int gi = rem >> 3, j = rem & 7;
+    const int r = gi / 3, g = gi - r * 3, x = 8 * g + j;
+    float v = 0.f;
+    if (n < Cout && gi < 21 && x < 21) v = wg[n * KPAD + r * 21 + x] * F_WSCALE;
+    const uint32_t hl = split1(v);
+    h = (uint16_t)(hl & 0xffffu);
+    l = (uint16_t)(hl >> 16);
+}
+
+// the LDS weight image of conv1_f16x3_kernel for every camera: [cam][hi piece | lo piece], F_WBYTES each
+__global__ __launch_bounds__(256) void conv1_wimg_kernel(const float* __restrict__ w, unsigned char* __restrict__ img, int Cout) {
+    const int cam = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 64 * F_NG * 8) return;
+    uint16_t h, l;
+    conv1_wimg_entry(w + (int64_t)cam * Cout * KPAD, Cout, e, h, l);
+    const int n = e / (F_NG * 8), rem = e - n * (F_NG * 8);
+    unsigned char* dst = img + (int64_t)cam * 2 * F_WBYTES;
+    *reinterpret_cast<uint16_t*>(dst + n * F_WROW + rem * 2) = h;
+    *reinterpret_cast<uint16_t*>(dst + F_WBYTES + n * F_WROW + rem * 2) = l;
+}
+
 template <int FMT>
 __global__ __launch_bounds__(256) void conv1_f16x3_kernel(Conv1Args p, int tiles_per_row, int tiles_per_cam) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -260,17 +285,21 @@ __global__ __launch_bounds__(256) void conv1_f16x3_kernel(Conv1Args p, int tiles
     const int li = lane & 31, lh = lane >> 5;
     const int prow = wave >> 1, phalf = wave & 1;
 
-    // weights: [Cout][148] (k = r*21 + x) -> [n][group r*3+g][8], split, scaled; everything else zero
-    const float* wg = p.w + (int64_t)cam * p.Cout * KPAD;
-    for (int e = t; e < 64 * F_NG * 8; e += 256) {
-        const int n = e / (F_NG * 8), rem = e - n * (F_NG * 8);
-        const int gi = rem >> 3, j = rem & 7;
-        const int r = gi / 3, g = gi - r * 3, x = 8 * g + j;
-        float v = 0.f;
-        if (n < p.Cout && gi < 21 && x < 21) v = wg[n * KPAD + r * 21 + x] * F_WSCALE;
-        const uint32_t hl = split1(v);
-        *reinterpret_cast<uint16_t*>(s_wh + n * F_WROW + gi * 16 + j * 2) = (uint16_t)(hl & 0xffffu);
-        *reinterpret_cast<uint16_t*>(s_wl + n * F_WROW + gi * 16 + j * 2) = (uint16_t)(hl >> 16);
+    // weights: [Cout][148] (k = r*21 + x) -> [n][group r*3+g][8], split, scaled; everything else zero.  The engine hands
+    // over the finished image (built once per weight update, conv1_wimg_kernel): a straight 46 KB copy instead of 44
+    // gather / split / 2-byte-store rounds per workgroup, which dominated the launch at small batches.
+    if (p.wimg) {
+        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + (int64_t)cam * 2 * F_WBYTES);
+        for (int e = t; e < 2 * F_WBYTES / 16; e += 256) reinterpret_cast<uint4*>(s_wh)[e] = src[e];
+    } else {
+        const float* wg = p.w + (int64_t)cam * p.Cout * KPAD;
+        for (int e = t; e < 64 * F_NG * 8; e += 256) {
+            uint16_t h, l;
+            conv1_wimg_entry(wg, p.Cout, e, h, l);
+            const int n = e / (F_NG * 8), rem = e - n * (F_NG * 8);
+            *reinterpret_cast<uint16_t*>(s_wh + n * F_WROW + rem * 2) = h;
+            *reinterpret_cast<uint16_t*>(s_wl + n * F_WROW + rem * 2) = l;
+        }
     }
     for (int e = t; e < 3 * 256; e += 256) s_lut[e] = (FMT == 0) ? split1(p.lut[e]) : 0u;
     for (int e = t; e < 2 * F_PATCH / 4; e += 256) reinterpret_cast<uint32_t*>(s_patch)[e] = 0u;
@@ -476,6 +505,16 @@ __global__ __launch_bounds__(256) void conv1_f16x3_kernel(Conv1Args p, int tiles
 
 }  // namespace
 
+int64_t conv1_wimg_bytes() { return 2 * F_WBYTES; }
+
+int launch_conv1_wimg(const float* w, void* img, int C, int Cout, hipStream_t st) {
+    // the pad bytes of each row (22 groups x 16 B = 352 of 368) are never read; zeroed so that the image is deterministic
+    if (hipMemsetAsync(img, 0, (size_t)C * 2 * F_WBYTES, st) != hipSuccess) return -3;
+    hipLaunchKernelGGL(conv1_wimg_kernel, dim3((64 * F_NG * 8 + 255) / 256, C), dim3(256), 0, st, w,
+                       reinterpret_cast<unsigned char*>(img), Cout);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 int launch_conv1(const Conv1Args& a, hipStream_t st, std::string* err) {
     if (a.Cout > 64 || a.Cout < 1) { if (err) *err = "conv1: Cout must be in 1..64"; return -2; }
     if (a.Ho != (a.H + 6 - 7) / 2 + 1 || a.Wo != (a.W + 6 - 7) / 2 + 1) { if (err) *err = "conv1: bad output size"; return -2; }
@@ -488,7 +527,10 @@ int launch_conv1(const Conv1Args& a, hipStream_t st, std::string* err) {
     if (prec == ACTMI_PREC_F16X3) {
         const int tiles_per_row = (a.Wo + F_TP - 1) / F_TP;
         const int tiles_per_cam = a.B * ((a.Ho + F_ROWS - 1) / F_ROWS) * tiles_per_row;
-        int gx = tiles_per_cam < 512 ? tiles_per_cam : 512;
+        static const int blocks_target = getenv("ACTMI_CONV1_BLOCKS") ? atoi(getenv("ACTMI_CONV1_BLOCKS")) : 512;   // tuning aid; 512 measured best at B = 1, 2, 8 (tools/conv1_blocks_sweep.sh)
+        int cap = blocks_target / (a.C > 0 ? a.C : 1);
+        if (cap < 1) cap = 1;
+        int gx = tiles_per_cam < cap ? tiles_per_cam : cap;
         const int per = (tiles_per_cam + gx - 1) / gx;
         gx = (tiles_per_cam + per - 1) / per;
         dim3 grid(gx, a.C);

@@ -98,6 +98,7 @@ struct actmi_ctx {
     // prepared weights
     std::vector<ConvLayer> convs;
     float *conv1_w = nullptr, *conv1_scale = nullptr, *conv1_bias = nullptr, *lut = nullptr;
+    float* conv1_wimg = nullptr;       // f16x3: conv1's LDS weight image per camera (launch_conv1_wimg), rebuilt with the weights
     float *pos_tokens = nullptr, *dec_t1 = nullptr, *dec_q = nullptr, *tmp_vec = nullptr;
     int* rowmap = nullptr;
     int rowmap_B = -1;

@@ -345,6 +345,7 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
     }
     const int D = g.hidden_dim, F = g.dim_feedforward, Q = g.num_queries, N = ctx->N, B = g.max_batch;
     if ((rc = dev_alloc(ctx, &ctx->conv1_w, (int64_t)C * w0 * 148))) return fail(rc);
+    if (ctx->gemm_prec == ACTMI_PREC_F16X3 && (rc = dev_alloc(ctx, &ctx->conv1_wimg, (int64_t)C * conv1_wimg_bytes() / 4))) return fail(rc);
     if ((rc = dev_alloc(ctx, &ctx->conv1_scale, (int64_t)C * w0))) return fail(rc);
     if ((rc = dev_alloc(ctx, &ctx->conv1_bias, (int64_t)C * w0))) return fail(rc);
     if ((rc = dev_alloc(ctx, &ctx->lut, 768))) return fail(rc);
@@ -423,6 +424,7 @@ int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st) {
     }
     if (ctx->gemm_prec == ACTMI_PREC_F16X3) {
         CHK(launch_split16(ctx->pbase, ctx->p16base, ctx->ptotal, W16_SCALE, st));
+        CHK(launch_conv1_wimg(ctx->conv1_w, ctx->conv1_wimg, C, w0, st));
         for (const ConvLayer& cl : ctx->convs)
             CHK(launch_split16(cl.w, cl.w16, (int64_t)C * cl.cout * cl.K, W16_SCALE, st));
     }
@@ -502,6 +504,7 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
     c1.bias = ctx->conv1_bias; c1.out = ctx->act1; c1.B = B; c1.C = C; c1.H = g.image_h; c1.W = g.image_w;
     c1.Ho = ctx->H1; c1.Wo = ctx->W1; c1.Cout = w0;
     c1.prec = ctx->gemm_prec;
+    c1.wimg = reinterpret_cast<const unsigned char*>(ctx->conv1_wimg);
     CHK(launch_conv1(c1, st, &ctx->err));
     CHK(launch_maxpool(ctx->act1, ctx->buf[0], C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
     float* cur = ctx->buf[0];

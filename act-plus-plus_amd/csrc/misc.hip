@@ -299,12 +299,24 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(SplitCombineArgs a)
     float v[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) v[e] = 0.f;
-    for (int s = 0; s < a.nsplit; ++s) {             // fixed order: run-to-run identical results
-        if (V == 4) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(src + s * a.split_stride);
+    // slices in groups of 8: all loads of a group in flight together, summed in index order (run-to-run identical);
+    // adding the zero of an absent slice changes nothing
+    for (int s0 = 0; s0 < a.nsplit; s0 += 8) {
+        float tv[8][V];
 #pragma unroll
-            for (int e = 0; e < V; ++e) v[e] += t[e];
-        } else v[0] += src[s * a.split_stride];
+        for (int u = 0; u < 8; ++u) {
+            const bool on = s0 + u < a.nsplit;
+            const float* q = src + (int64_t)(on ? s0 + u : s0) * a.split_stride;
+            if (V == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(q);
+#pragma unroll
+                for (int e = 0; e < V; ++e) tv[u][e] = on ? t[e] : 0.f;
+            } else tv[u][0] = on ? q[0] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] += tv[u][e];
     }
 #pragma unroll
     for (int e = 0; e < V; ++e) {

@@ -506,6 +506,7 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
         c1.bias = ctx->conv1_bias; c1.out = ctx->act1; c1.B = B; c1.C = C; c1.H = g.image_h; c1.W = g.image_w;
         c1.Ho = ctx->H1; c1.Wo = ctx->W1; c1.Cout = w0;
         c1.prec = ctx->gemm_prec;
+        c1.wimg = reinterpret_cast<const unsigned char*>(ctx->conv1_wimg);
         CHK(launch_conv1(c1, st, &ctx->err));
         CHK(launch_maxpool_idx(ctx->act1, T.pool, T.pool_arg, C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
     }
