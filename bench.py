@@ -147,6 +147,19 @@ def main():
     L.profile_enable(False)
     prof = L.profile_report()
     log(f"timed region done: {(t1 - t0) / args.steps * 1e3:.2f} ms/step")
+    # per-step latency distribution (median + p10/p90, event-timed), after the timed region: each step
+    # bracketed by events on the stream it runs on
+    lat = None
+    if rank == 0:
+        n_lat = max(10, min(200, args.steps))
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_lat)]
+        for e0, e1 in evs:
+            e0.record()
+            step()
+            e1.record()
+        torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        lat = {"n": n_lat, "p10": ts[int(0.1 * (n_lat - 1))], "p50": ts[n_lat // 2], "p90": ts[int(0.9 * (n_lat - 1))]}
     elapsed = t1 - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -199,6 +212,7 @@ def main():
                            "frac_of_fp32_matrix_peak": value / world * GFLOP_PER_SAMPLE_LIVE / 1e3 / PEAK_FP32_MATRIX_TFLOPS,
                            "gpu_kernel_ms_per_step": gpu_ms / args.steps},
             "kernels": kernels,
+            "step_latency_ms": lat,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, B, args.cpu_iters)
