@@ -179,6 +179,7 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
         int S = tiles < ctx->sk_maxtiles ? (int)((ctx->sk_target + tiles - 1) / tiles) : 1;
         if (S > 8) S = 8;
         if (S > nk / ctx->sk_minnk) S = nk / ctx->sk_minnk;
+        while (S >= 2 && (S - 1) * ((nk + S - 1) / S) >= nk) --S;              // every split must own a K tile
         const int64_t slice = (int64_t)a.M * a.N;
         if (S >= 2 && slice * groups * S <= ctx->splitk_ws_floats && (a.N & 3) == 0) {
             GemmArgs p = a;
