@@ -287,9 +287,10 @@ def test_layernorm(M, D):
     assert rel_err(g1, e1) < 2e-6 and rel_err(g2, e2) < 4e-6
 
 
-def test_maxpool_bit_exact():
+@pytest.mark.parametrize("H,W", [(23, 31), (24, 32), (22, 29), (240, 320)])
+def test_maxpool_bit_exact(H, W):
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(3, 64, 23, 31, generator=g)
+    x = torch.randn(3, 64, H, W, generator=g)
     exp = F.max_pool2d(x, 3, 2, 1)
     got = ops.maxpool3x3s2(x.permute(0, 2, 3, 1).contiguous().to(dev()))
     assert torch.equal(got.permute(0, 3, 1, 2).cpu(), exp)      # max is order independent: bit exact
