@@ -51,6 +51,8 @@ struct Conv1Args {
     int B, C, H, W, Ho, Wo, Cout;
     int prec = 0;         // ACTMI_PREC_* (0 = environment / native fp32)
     const unsigned char* wimg = nullptr;   // f16x3 only, optional: launch_conv1_wimg's image of w (C x conv1_wimg_bytes())
+    int vpool = 0;        // f16x3 only: write max over conv rows (2a-1, 2a, 2a+1) -> out [C][B][Ho/2][Wo][Cout] (pool's vertical half)
+    int vpool_nseg = 1;   // set by the launcher
 };
 int64_t conv1_wimg_bytes();
 int launch_conv1_wimg(const float* w, void* img, int C, int Cout, hipStream_t st);
@@ -71,6 +73,8 @@ int launch_conv3x3_c64(const Conv3Args& a, hipStream_t st, std::string* err);
 
 // ---- 3x3/s2/p1 max pool NHWC (pool.hip) -----------------------------------------------------
 int launch_maxpool(const float* in, float* out, int nimg, int H, int W, int C, int Ho, int Wo, hipStream_t st);
+// horizontal half of the 3x3/s2/p1 pool on a vertically pooled map: out[h][pw] = max(in[h][2pw-1 .. 2pw+1])
+int launch_hpool(const float* in, float* out, int nrows, int W, int C, int Wo, hipStream_t st);
 int launch_maxpool_idx(const float* in, float* out, uint8_t* arg, int nimg, int H, int W, int C, int Ho, int Wo, hipStream_t st);
 int launch_maxpool_bwd_idx(const uint8_t* arg, const float* dy, float* dx, int nimg, int H, int W, int C, int Ho, int Wo,
                            hipStream_t st);

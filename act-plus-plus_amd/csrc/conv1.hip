@@ -416,23 +416,52 @@ __global__ __launch_bounds__(256) void conv1_f16x3_kernel(Conv1Args p, int tiles
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile < tiles_per_cam) {
+    // Tile walk.  Plain mode: tiles blockIdx.x, +gridDim.x, ... in any order.  vpool mode (inference): a workgroup owns a
+    // chain = (image, 64-column strip, segment of row pairs) and walks DOWN it, one row pair per step, so that the lower
+    // conv row of the previous step stays in registers: the vertical 3-max of the 3x3/s2 pool (rows 2a-1, 2a, 2a+1) is
+    // formed in the epilogue and only the vertically pooled map [Ho/2][Wo][Cout] is written -- half the bytes, and the
+    // pool pass that follows reads half as much.  A chain that does not start at the top first computes the row pair above
+    // it without storing (halo).  Values are post-ReLU (>= 0), so 0 stands in for the padded row above the image.
+    int tile = blockIdx.x, tile_stride = gridDim.x, tile_end = tiles_per_cam, store_from = 0;
+    if (p.vpool) {
+        const int chains_per_img = tiles_per_row * p.vpool_nseg;
+        const int b = blockIdx.x / chains_per_img, rem = blockIdx.x - b * chains_per_img;
+        const int strip = rem / p.vpool_nseg, seg = rem - strip * p.vpool_nseg;
+        const int len = (hpairs + p.vpool_nseg - 1) / p.vpool_nseg;
+        const int hp0 = seg * len, hp1 = (hp0 + len < hpairs) ? hp0 + len : hpairs;
+        const int first = hp0 > 0 ? hp0 - 1 : 0;
+        tile = (b * hpairs + first) * tiles_per_row + strip;
+        tile_stride = tiles_per_row;
+        tile_end = hp0 < hp1 ? (b * hpairs + hp1 - 1) * tiles_per_row + strip + 1 : 0;      // empty segment: no steps
+        store_from = (b * hpairs + hp0) * tiles_per_row + strip;
+    }
+    if (tile < tile_end) {
         fetch(tile);
         commit(tile, s_patch);
     }
     __syncthreads();
     int cur = 0;
     const unsigned char* bbase = s_wh + li * F_WROW + lh * 16;
-    for (; tile < tiles_per_cam; tile += gridDim.x) {
-        const int next = tile + gridDim.x;
-        const bool has_next = next < tiles_per_cam;
+    float prev[2][2][4];                  // vpool: lower conv row of the previous step (this lane's channel, 8 columns)
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+            for (int c_ = 0; c_ < 4; ++c_) prev[a_][b_][c_] = 0.f;
+    for (; tile < tile_end; tile += tile_stride) {
+        const int next = tile + tile_stride;
+        const bool has_next = next < tile_end;
         if (has_next) fetch(next);
         int b, ho0, wo0;
         tile_coords(tile, b, ho0, wo0);
         const int64_t oimg = (int64_t)cam * p.B + b;
         {
-            const unsigned char* abase = s_patch + cur * F_PATCH + (2 * prow) * 2 * F_RB + 12 * (phalf * 32 + li);
+            // plain: wave = (row, 32-column half), lane pixel = column.  vpool: wave = 16-column quarter, lane pixel =
+            // (row = li >> 4, column = li & 15), so that both rows of a column sit in the same lane's accumulators
+            const unsigned char* abase = p.vpool
+                ? s_patch + cur * F_PATCH + (2 * (li >> 4)) * 2 * F_RB + 12 * (wave * 16 + (li & 15))
+                : s_patch + cur * F_PATCH + (2 * prow) * 2 * F_RB + 12 * (phalf * 32 + li);
             f32x16 acc[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -460,8 +489,35 @@ __global__ __launch_bounds__(256) void conv1_f16x3_kernel(Conv1Args p, int tiles
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, acc[nt], 0, 0, 0);
                 }
             }
+            if (p.vpool) {
+                // accumulator register e = 4*gq + i holds pixel 8*gq + 4*lh + i: gq 0,1 = upper row, gq 2,3 = lower row
+                const int q4 = (li >> 2) * 4, k = li & 3;
+                const bool do_store = tile >= store_from;            // block-uniform
+                const int hp = ho0 >> 1;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                    for (int gq = 0; gq < 2; ++gq) {
+                        float v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float up = fmaxf(acc[nt][4 * gq + i] * sc[nt] + bi[nt], 0.f);
+                            const float lo = fmaxf(acc[nt][4 * (gq + 2) + i] * sc[nt] + bi[nt], 0.f);
+                            v[i] = fmaxf(prev[nt][gq][i], fmaxf(up, lo));
+                            prev[nt][gq][i] = lo;
+                        }
+                        quad_transpose(v[0], v[1], v[2], v[3], k);
+                        const int wo = wo0 + wave * 16 + 8 * gq + 4 * lh + k;
+                        const int nb = nt * 32 + q4;
+                        if (do_store && wo < p.Wo && nb < p.Cout) {
+                            float* dst = p.out + ((oimg * (p.Ho >> 1) + hp) * (int64_t)p.Wo + wo) * p.Cout + nb;
+                            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                        }
+                    }
+                }
+            }
             const int ho = ho0 + prow;
-            if (ho < p.Ho) {
+            if (!p.vpool && ho < p.Ho) {
                 // C layout: lane = channel, registers = pixels.  A 4x4 transpose inside each quad of lanes (4 channels x
                 // 4 consecutive pixels, two DPP quad-permute stages) gives every lane 4 consecutive channels of ONE
                 // pixel: 16-byte stores instead of 4-byte ones (the scalar form ran this epilogue at ~1.5 TB/s).
@@ -533,6 +589,16 @@ int launch_conv1(const Conv1Args& a, hipStream_t st, std::string* err) {
         int gx = tiles_per_cam < cap ? tiles_per_cam : cap;
         const int per = (tiles_per_cam + gx - 1) / gx;
         gx = (tiles_per_cam + per - 1) / per;
+        Conv1Args av = a;
+        if (a.vpool) {
+            if ((a.Ho & 1) || (a.Cout & 3)) { if (err) *err = "conv1: vpool needs an even output height and Cout % 4 == 0"; return -2; }
+            const int hpairs = a.Ho / 2;
+            int nseg = blocks_target / (a.C * a.B * tiles_per_row > 0 ? a.C * a.B * tiles_per_row : 1);
+            if (nseg > hpairs / 4) nseg = hpairs / 4;            // chains of >= 4 row pairs (+1 halo step); only B = 1 gets there
+            if (nseg < 1) nseg = 1;
+            av.vpool_nseg = nseg;
+            gx = a.B * tiles_per_row * nseg;
+        }
         dim3 grid(gx, a.C);
         prof_begin(a.fmt == 0 ? "conv1_f16x3_kernel<0>" : "conv1_f16x3_kernel<1>", 2.0 * a.B * a.C * a.Ho * a.Wo * a.Cout * 147.0,
                    (double)a.B * a.C * ((double)a.H * a.W * 3 * (a.fmt == 0 ? 1 : 4) + 4.0 * a.Ho * a.Wo * a.Cout), st);
@@ -545,9 +611,10 @@ int launch_conv1(const Conv1Args& a, hipStream_t st, std::string* err) {
             }
             attr16 = true;
         }
-        if (a.fmt == 0) hipLaunchKernelGGL(conv1_f16x3_kernel<0>, grid, dim3(256), F_SMEM, st, a, tiles_per_row, tiles_per_cam);
-        else hipLaunchKernelGGL(conv1_f16x3_kernel<1>, grid, dim3(256), F_SMEM, st, a, tiles_per_row, tiles_per_cam);
+        if (a.fmt == 0) hipLaunchKernelGGL(conv1_f16x3_kernel<0>, grid, dim3(256), F_SMEM, st, av, tiles_per_row, tiles_per_cam);
+        else hipLaunchKernelGGL(conv1_f16x3_kernel<1>, grid, dim3(256), F_SMEM, st, av, tiles_per_row, tiles_per_cam);
     } else {
+    if (a.vpool) { if (err) *err = "conv1: vpool needs prec f16x3"; return -2; }
     const int tiles_per_row = (a.Wo + TILE_P - 1) / TILE_P;
     const int tiles_per_cam = a.B * a.Ho * tiles_per_row;
     int gx = tiles_per_cam < 512 ? tiles_per_cam : 512;

@@ -89,6 +89,7 @@ struct actmi_ctx {
     int gemm_prec = 0;                 // ACTMI_PREC_* used by the forward GEMMs of this handle
     float* splitk_ws = nullptr;        // slices of the forward GEMMs whose contraction is split to fill the chip
     int64_t splitk_ws_floats = 0;
+    int conv1_vpool = 1;               // inference: conv1 emits the vertical half of the max pool (ACTMI_CONV1_VPOOL=0: off)
     int fwd_splitk = 1;                // 0: never split a forward contraction (ACTMI_FWD_SPLITK=0)
     int sk_target = 1536, sk_minnk = 12, sk_maxtiles = 768;     // split heuristic (tuning aids ACTMI_FWD_SPLITK_*)
     int64_t ptotal = 0;

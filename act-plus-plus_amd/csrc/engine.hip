@@ -306,6 +306,7 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
         ctx->gemm_prec = (e && e[0] == 'f' && e[1] == '3') ? ACTMI_PREC_F32 : ACTMI_PREC_F16X3;
         if (ctx->ptotal & 3) { ctx->err = "parameter arena not a multiple of 4 floats"; return fail(ACTMI_E_LAUNCH); }
         if ((rc = dev_alloc(ctx, &ctx->p16base, ctx->ptotal))) return fail(rc);
+        { const char* vp = getenv("ACTMI_CONV1_VPOOL"); ctx->conv1_vpool = !(vp && vp[0] == '0'); }
         const char* sk = getenv("ACTMI_FWD_SPLITK");
         ctx->fwd_splitk = !(sk && sk[0] == '0');
         if (const char* e2 = getenv("ACTMI_FWD_SPLITK_TARGET")) ctx->sk_target = atoi(e2);
@@ -506,8 +507,16 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
     c1.Ho = ctx->H1; c1.Wo = ctx->W1; c1.Cout = w0;
     c1.prec = ctx->gemm_prec;
     c1.wimg = reinterpret_cast<const unsigned char*>(ctx->conv1_wimg);
-    CHK(launch_conv1(c1, st, &ctx->err));
-    CHK(launch_maxpool(ctx->act1, ctx->buf[0], C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
+    // inference never needs conv1's own map: the stem emits the vertical half of the max pool (half the bytes) and a
+    // row-wise pass finishes it.  Same maxima, so the result is bit-identical to conv1 -> 3x3 pool.
+    if (ctx->conv1_vpool && ctx->stop_stage != "conv1" && ctx->gemm_prec == ACTMI_PREC_F16X3 && (ctx->H1 & 1) == 0 && (w0 & 3) == 0 && ctx->H2 == ctx->H1 / 2) {
+        c1.vpool = 1;
+        CHK(launch_conv1(c1, st, &ctx->err));
+        CHK(launch_hpool(ctx->act1, ctx->buf[0], C * B * ctx->H2, ctx->W1, w0, ctx->W2, st));
+    } else {
+        CHK(launch_conv1(c1, st, &ctx->err));
+        CHK(launch_maxpool(ctx->act1, ctx->buf[0], C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
+    }
     float* cur = ctx->buf[0];
     float* s1 = ctx->buf[1];
     float* s2 = ctx->buf[2];

@@ -30,6 +30,27 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
         reinterpret_cast<f32x4*>(out)[idx] = m;
     }
 }
+// horizontal half of the pool: rows are independent; each thread produces 4 channels of one output pixel
+__global__ __launch_bounds__(256) void hpool_kernel(const float* __restrict__ in, float* __restrict__ out, int W, int C4,
+                                                    int Wo, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        const int64_t pix = idx / C4;
+        const int wo = (int)(pix % Wo);
+        const int64_t row = pix / Wo;
+        const f32x4* src = reinterpret_cast<const f32x4*>(in) + row * W * C4 + c4;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int wi = 2 * wo - 1 + s;
+            if ((unsigned)wi >= (unsigned)W) continue;
+            const f32x4 v = src[(int64_t)wi * C4];
+            m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+        }
+        reinterpret_cast<f32x4*>(out)[idx] = m;
+    }
+}
 // training variant: also records, per output element, WHICH of the 9 window positions (r*3+s) held the maximum (the
 // first one in scan order, ATen's tie rule) so that the backward pass is a gather of at most 4 (byte, float) pairs per
 // input element instead of recomputing four 9-element maxima
@@ -85,6 +106,18 @@ int launch_maxpool(const float* in, float* out, int nimg, int H, int W, int C, i
     if (blocks > 256 * 16) blocks = 256 * 16;
     prof_begin("maxpool_kernel", 0.0, 4.0 * nimg * C * ((double)H * W + (double)Ho * Wo), st);
     hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, H, W, C / 4, Ho, Wo, total);
+    prof_end(st);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_hpool(const float* in, float* out, int nrows, int W, int C, int Wo, hipStream_t st) {
+    if (C & 3) return -2;
+    const int64_t total = (int64_t)nrows * Wo * (C / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) return 0;
+    prof_begin("hpool_kernel", 0.0, 4.0 * nrows * C * ((double)W + (double)Wo), st);
+    hipLaunchKernelGGL(hpool_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, W, C / 4, Wo, total);
     prof_end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

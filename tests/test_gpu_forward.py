@@ -176,6 +176,26 @@ def test_single_query_split_contraction_matches_unsplit(monkeypatch):
     assert 0.0 < d <= 3e-5                    # > 0: the split path did run
 
 
+@pytest.mark.parametrize("cams,batch", [(["a", "b"], 3), (["top"], 1)])
+def test_stem_with_fused_vertical_pool_is_bit_identical(monkeypatch, cams, batch):
+    """Inference lets conv1 write max over conv rows (2a-1, 2a, 2a+1) and finishes the 3x3/s2 pool row-wise; the same
+    maxima as conv1 -> max pool, so a_hat must not change by a single bit (full-size images: 5 column strips, several
+    row segments with a halo step each)."""
+    from actmi.config import ACTConfig
+    cfg = ACTConfig(camera_names=cams, enc_layers=1, dim_feedforward=256)
+    sd_np = W.generate_state_dict(cfg, seed=4)
+    inp = W.generate_inputs(cfg, batch, seed=8)
+    q = torch.from_numpy(inp["qpos"]).cuda()
+    im = torch.from_numpy(inp["image_u8"]).cuda()
+    eng = _engine(cfg, sd_np, batch, "f16x3")
+    a = eng.forward_infer(q, im).clone()
+    del eng
+    monkeypatch.setenv("ACTMI_CONV1_VPOOL", "0")
+    eng = _engine(cfg, sd_np, batch, "f16x3")
+    b = eng.forward_infer(q, im).clone()
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_state_dict_round_trip_and_errors():
     from actmi.config import tiny_config
     cfg = tiny_config()
