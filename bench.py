@@ -186,7 +186,7 @@ def main():
         # WRITE_SIZE; gfx950 correction applied) of this same command and committed under profiles/; null if absent
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_i_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_j_traffic.json")))
             traffic = tj["kernels"][dom["name"]]["traffic_bytes_per_launch"] if B == 8 else None
         except Exception:
             traffic = None
