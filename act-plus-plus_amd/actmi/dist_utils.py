@@ -22,6 +22,12 @@ def init_from_env():
     return rank, world, local_rank
 
 
+def barrier():
+    """No-op without a process group."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
 def all_gather_rows(local: torch.Tensor, counts):
     """Gather variable-length [n_r, k] float tensors from every rank into one [sum n_r, k] CPU tensor
     (the single collective of the eval path: per-episode (return, highest_reward))."""

@@ -30,8 +30,11 @@ class ACTEngine:
         self.cfg = cfg.validate()
         self.device = torch.device(device)
         self.max_batch = int(max_batch)
+        if self.device.type != "cuda":
+            raise ValueError(f"ACTEngine device must be a cuda device, got {device!r}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = L.load()
-        torch.cuda.set_device(self.device)
         c = L.ActmiConfig(num_cams=cfg.num_cams, image_h=cfg.image_h, image_w=cfg.image_w, base_width=cfg.base_width,
                           hidden_dim=cfg.hidden_dim, nheads=cfg.nheads, dim_feedforward=cfg.dim_feedforward,
                           enc_layers=cfg.enc_layers, dec_layers=cfg.dec_layers, num_queries=cfg.num_queries,
@@ -40,7 +43,10 @@ class ACTEngine:
                           enable_training=1 if training else 0, kl_weight=float(cfg.kl_weight),
                           vq=1 if cfg.vq else 0, vq_class=int(cfg.vq_class or 0), vq_dim=int(cfg.vq_dim or 0))
         h = C.c_void_p()
-        rc = self.lib.actmi_create(C.byref(c), C.byref(h))
+        # the handle binds to the device that is current at create time; the process-wide current device is left alone
+        # (one process may hold engines on several GPUs; every later call switches to the handle's device by itself)
+        with torch.cuda.device(self.device):
+            rc = self.lib.actmi_create(C.byref(c), C.byref(h))
         if rc != 0:
             raise RuntimeError(f"actmi_create failed ({rc}): {self.lib.actmi_last_error(None).decode()}")
         self.h = h
@@ -51,6 +57,15 @@ class ACTEngine:
         # attributes imitate_episodes.py touches on policy.model
         self.num_queries = cfg.num_queries
         self.encoder = None if cfg.no_encoder else True
+
+    def _sp(self):
+        """The caller's current stream ON THE ENGINE'S DEVICE (never another device's stream)."""
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check_dev(self, **tensors):
+        for name, t in tensors.items():
+            if t is not None and t.device != self.device:
+                raise ValueError(f"{name} lives on {t.device} but this engine is bound to {self.device}")
 
     def __del__(self):
         try:
@@ -100,7 +115,7 @@ class ACTEngine:
         return out
 
     def finalize(self):
-        L.check(self.lib.actmi_finalize(self.h, L.current_stream_ptr()), self.h, "finalize")
+        L.check(self.lib.actmi_finalize(self.h, self._sp()), self.h, "finalize")
         self._finalized = True
 
     # ---- forward ------------------------------------------------------------------------------
@@ -128,6 +143,7 @@ class ACTEngine:
             raise ValueError(f"batch {B} > max_batch {self.max_batch}")
         if not (qpos.is_cuda and image.is_cuda):
             raise ValueError("qpos and image must be CUDA tensors on the engine's device")
+        self._check_dev(qpos=qpos, image=image, out=out)
         qpos = qpos.to(torch.float32).contiguous()
         image = image.contiguous()
         fmt = self._image_fmt(image, B)
@@ -142,10 +158,10 @@ class ACTEngine:
             code = vq_sample.to(device=qpos.device, dtype=torch.float32).reshape(B, cfg.vq_class * cfg.vq_dim).contiguous()
             L.check(self.lib.actmi_forward_infer_vq(self.h, C.c_void_p(qpos.data_ptr()), C.c_void_p(image.data_ptr()), fmt,
                                                     B, C.c_void_p(code.data_ptr()), C.c_void_p(out.data_ptr()),
-                                                    L.current_stream_ptr()), self.h, "forward_infer_vq")
+                                                    self._sp()), self.h, "forward_infer_vq")
         else:
             L.check(self.lib.actmi_forward_infer(self.h, C.c_void_p(qpos.data_ptr()), C.c_void_p(image.data_ptr()), fmt, B,
-                                                 C.c_void_p(out.data_ptr()), L.current_stream_ptr()), self.h,
+                                                 C.c_void_p(out.data_ptr()), self._sp()), self.h,
                     "forward_infer")
         if _CHECK_FINITE and not bool(torch.isfinite(out).all()):
             # f16x3 needs finite operands with |x| < 65504: an activation beyond that shows up here
@@ -209,6 +225,7 @@ class ACTEngine:
         cfg = self.cfg
         B = qpos.shape[0]
         Q, A, Lz = cfg.num_queries, cfg.action_dim, cfg.latent_in_dim
+        self._check_dev(qpos=qpos, image=image, actions=actions, is_pad=is_pad)
         qpos = qpos.to(torch.float32).contiguous()
         image = image.contiguous()
         fmt = self._image_fmt(image, B)
@@ -230,7 +247,7 @@ class ACTEngine:
             self.h, C.c_void_p(qpos.data_ptr()), C.c_void_p(image.data_ptr()), fmt, C.c_void_p(actions.data_ptr()),
             C.c_void_p(is_pad_u8.data_ptr()), C.c_void_p(eps.data_ptr() if eps is not None else 0), C.c_uint64(dropout_seed),
             float(dropout_p), B, C.c_void_p(losses.data_ptr()), C.c_void_p(a_hat.data_ptr()), C.c_void_p(mu.data_ptr()),
-            C.c_void_p(logvar.data_ptr()), L.current_stream_ptr()), self.h, "forward_train")
+            C.c_void_p(logvar.data_ptr()), self._sp()), self.h, "forward_train")
         out = {"l1": losses[0], "kl": losses[1], "loss": losses[2], "a_hat": a_hat}
         if cfg.vq:
             probs, binaries = mu.view(B, cfg.vq_class, cfg.vq_dim), logvar.view(B, cfg.vq_class, cfg.vq_dim)
@@ -241,14 +258,14 @@ class ACTEngine:
         return out
 
     def backward(self, loss_scale: float = 1.0):
-        L.check(self.lib.actmi_backward(self.h, float(loss_scale), L.current_stream_ptr()), self.h, "backward")
+        L.check(self.lib.actmi_backward(self.h, float(loss_scale), self._sp()), self.h, "backward")
 
     def zero_grad(self):
-        L.check(self.lib.actmi_zero_grad(self.h, L.current_stream_ptr()), self.h, "zero_grad")
+        L.check(self.lib.actmi_zero_grad(self.h, self._sp()), self.h, "zero_grad")
 
     def adamw_step(self, lr, lr_backbone, weight_decay=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, step=1):
         L.check(self.lib.actmi_adamw_step(self.h, lr, lr_backbone, weight_decay, beta1, beta2, eps, int(step),
-                                          L.current_stream_ptr()), self.h, "adamw_step")
+                                          self._sp()), self.h, "adamw_step")
 
     def grad_arena(self) -> torch.Tensor:
         """Flat float32 view (no copy) of the whole gradient arena, for data-parallel all-reduce."""
@@ -267,7 +284,7 @@ class ACTEngine:
         """Copy of the gradient of one state_dict entry (shape of the parameter)."""
         p, n = C.c_void_p(), C.c_int64()
         L.check(self.lib.actmi_grad_ptr(self.h, key.encode(), C.byref(p), C.byref(n)), self.h, f"grad_ptr({key})")
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(self.device)
         return _from_ptr(p.value, n.value, self.device).clone().view(self.spec[key])
 
     # ---- debug --------------------------------------------------------------------------------
@@ -278,10 +295,10 @@ class ACTEngine:
         p, n = C.c_void_p(), C.c_int64()
         L.check(self.lib.actmi_debug_tensor(self.h, name.encode(), C.byref(p), C.byref(n)), self.h, f"debug_tensor({name})")
         t = torch.empty(n.value, dtype=torch.float32, device=self.device)
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(self.device)
         src = _from_ptr(p.value, n.value, self.device)     # wrap the raw pointer, then D2D copy through torch
         t.copy_(src)
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(self.device)
         return t
 
 

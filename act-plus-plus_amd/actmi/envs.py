@@ -3,8 +3,12 @@
 The reference steps dm_control/MuJoCo envs (sim_env.py:20-116) on the host; those packages are absent offline, so
 throughput and plumbing runs use ``SyntheticEnv``: same interface (``reset()/step(action)`` returning a timestep
 with ``.observation['qpos']``, ``.observation['images'][cam]`` HWC uint8 and ``.reward``; ``.task.max_reward``), a
-deterministic function of (pose, step).  ``make_sim_env`` returns the real env when dm_control is importable.
+deterministic function of (pose, step).  ``make_sim_env`` wraps the real simulator (``SimEnvAdapter``) whenever a module
+with the reference's ``sim_env`` interface is importable.
 """
+import importlib
+import os
+import threading
 import types
 
 import numpy as np
@@ -52,15 +56,62 @@ class SyntheticEnv:
         return _TimeStep(self._obs(), reward)
 
 
-def make_sim_env(task_name, camera_names, pose, seed=0, height=480, width=640):
-    """reference sim_env.py:20-52 when dm_control exists, else SyntheticEnv."""
+class SimEnvAdapter:
+    """The reference's simulator behind the batched rollout loop.
+
+    ``mod`` is a module with the reference's ``sim_env`` interface (sim_env.py:18-52): ``make_sim_env(task_name)`` returning a
+    dm_control ``control.Environment`` and the module global ``BOX_POSE = [None]`` that the task's ``initialize_episode``
+    reads during ``reset()``.  The reference sets ``BOX_POSE[0]`` right before ``env.reset()`` (imitate_episodes.py:324-329);
+    here the pose was pre-drawn in the reference's RNG order and is installed under a lock, because the E envs of a batch are
+    reset from host threads and ``BOX_POSE`` is one global per module."""
+
+    _lock = threading.Lock()
+
+    def __init__(self, mod, task_name, pose):
+        self.mod = mod
+        self.pose = np.asarray(pose, dtype=np.float64)
+        self.env = mod.make_sim_env(task_name)
+        self.task = self.env.task                       # .max_reward (imitate_episodes.py:316)
+
+    def reset(self):
+        with SimEnvAdapter._lock:
+            self.mod.BOX_POSE[0] = self.pose
+            return self.env.reset()
+
+    def step(self, action):
+        return self.env.step(action)
+
+
+_warned_synthetic = [False]
+
+
+def load_sim_env_module(name=None):
+    """Import the user-supplied simulator module (default ``sim_env``, override with ACTMI_SIM_ENV_MODULE): the reference's
+    own sim_env.py on sys.path works as is.  Returns None when it (or dm_control / mujoco underneath it) is not importable."""
+    name = name or os.environ.get("ACTMI_SIM_ENV_MODULE", "sim_env")
     try:
-        import dm_control  # noqa: F401
-        have_dm = True
+        mod = importlib.import_module(name)
     except Exception:
-        have_dm = False
-    if have_dm:
-        raise NotImplementedError("dm_control is present: plug the reference's sim_env.make_sim_env here")
+        return None
+    if not (hasattr(mod, "make_sim_env") and hasattr(mod, "BOX_POSE")):
+        return None
+    return mod
+
+
+def make_sim_env(task_name, camera_names, pose, seed=0, height=480, width=640, synthetic=None):
+    """reference sim_env.py:20-52 + the BOX_POSE hand-off of imitate_episodes.py:324-327 when a ``sim_env`` module is
+    importable; otherwise (or with ``synthetic=True`` / ACTMI_SYNTHETIC_ENV=1) the ``SyntheticEnv`` stand-in, announced once:
+    its rewards are pseudo-dynamics, so success rates from it are plumbing / throughput figures, not task results."""
+    if synthetic is None:
+        synthetic = os.environ.get("ACTMI_SYNTHETIC_ENV") == "1"
+    mod = None if synthetic else load_sim_env_module()
+    if mod is not None:
+        return SimEnvAdapter(mod, task_name, pose)
+    if not _warned_synthetic[0]:
+        _warned_synthetic[0] = True
+        why = "requested" if synthetic else "no importable sim_env module (dm_control / mujoco absent)"
+        print(f"[actmi.envs] SyntheticEnv stand-in ({why}): rewards are pseudo-dynamics -- throughput / plumbing only, "
+              "NOT task success rates")
     return SyntheticEnv(camera_names, pose, height, width, seed=seed)
 
 

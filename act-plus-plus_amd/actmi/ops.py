@@ -228,6 +228,10 @@ class TemporalEnsemble:
         """all_actions [E,Q,A] f32 cuda -> raw_action [E,A] f64 (same dtype as the reference's raw_action)."""
         lib = L.load()
         a = all_actions.contiguous()
-        L.check(lib.actmi_ensemble_step(_p(self.ring), _p(self.t), _p(a), self.k, _p(self.out), _p(self.populated),
-                                        self.E, self.Q, self.A, L.current_stream_ptr()), None, "ensemble_step")
+        dev = self.ring.device
+        if a.device != dev:
+            raise ValueError(f"all_actions lives on {a.device} but this ensemble is bound to {dev}")
+        with torch.cuda.device(dev):          # the kernel launches on the ring's device whatever the caller left current
+            L.check(lib.actmi_ensemble_step(_p(self.ring), _p(self.t), _p(a), self.k, _p(self.out), _p(self.populated),
+                                            self.E, self.Q, self.A, L.current_stream_ptr()), None, "ensemble_step")
         return self.out

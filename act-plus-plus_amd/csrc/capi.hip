@@ -7,6 +7,18 @@ namespace {
 thread_local std::string g_op_error;
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 int bad(actmi_ctx* h, const std::string& m, int code = ACTMI_E_INVALID) { h->err = m; return code; }
+// a handle is bound to the device it was created on: calls made while another device is current switch to it for
+// their duration (one process driving several GPUs; torch's current device is whatever the caller left it at)
+struct DevGuard {
+    int prev = -1, want;
+    explicit DevGuard(int dev) : want(dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want) (void)hipSetDevice(want);
+    }
+    ~DevGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+};
+// entry of every call on a handle: no stale message from an earlier failure, handle's device current
+#define ENTER(h) (h)->err.clear(); DevGuard _dev_guard((h)->device)
 }  // namespace
 
 extern "C" {
@@ -21,7 +33,11 @@ int actmi_create(const actmi_config* cfg, actmi_handle* out) {
     }
 }
 
-int actmi_destroy(actmi_handle h) { return engine_destroy(h); }
+int actmi_destroy(actmi_handle h) {
+    if (!h) return 0;
+    DevGuard g(h->device);
+    return engine_destroy(h);
+}
 
 const char* actmi_last_error(actmi_handle h) { return h ? h->err.c_str() : engine_create_error(); }
 
@@ -39,6 +55,7 @@ int actmi_param_info(actmi_handle h, int index, const char** key, int64_t* shape
 
 int actmi_set_param(actmi_handle h, const char* key, const void* src, const int64_t* shape, int ndim, int is_device) {
     if (!h || !key || !src) return ACTMI_E_INVALID;
+    ENTER(h);
     auto it = h->index.find(key);
     if (it == h->index.end()) return bad(h, std::string("unknown state_dict key: ") + key);
     const Param& p = h->params[it->second];
@@ -47,7 +64,9 @@ int actmi_set_param(actmi_handle h, const char* key, const void* src, const int6
         for (int i = 0; i < ndim; ++i)
             if (shape[i] != p.shape[i]) return bad(h, std::string("shape mismatch for ") + key);
     }
-    hipError_t e = hipMemcpy(h->pbase + p.off, src, p.numel * sizeof(float),
+    // ordered against work in flight on any stream (a parameter must not change under a running kernel)
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(h->pbase + p.off, src, p.numel * sizeof(float),
                              is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
     if (e != hipSuccess) return bad(h, std::string("hipMemcpy: ") + hipGetErrorString(e), ACTMI_E_LAUNCH);
     h->finalized = false;
@@ -56,20 +75,28 @@ int actmi_set_param(actmi_handle h, const char* key, const void* src, const int6
 
 int actmi_get_param(actmi_handle h, const char* key, void* dst, int64_t nbytes, int is_device) {
     if (!h || !key || !dst) return ACTMI_E_INVALID;
+    ENTER(h);
     auto it = h->index.find(key);
     if (it == h->index.end()) return bad(h, std::string("unknown state_dict key: ") + key);
     const Param& p = h->params[it->second];
     if (nbytes != p.numel * (int64_t)sizeof(float)) return bad(h, std::string("size mismatch for ") + key);
-    hipError_t e = hipMemcpy(dst, h->pbase + p.off, nbytes, is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
+    // ordered against an optimizer step in flight on any stream (no checkpoint of half-updated weights)
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(dst, h->pbase + p.off, nbytes, is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
     if (e != hipSuccess) return bad(h, std::string("hipMemcpy: ") + hipGetErrorString(e), ACTMI_E_LAUNCH);
     return 0;
 }
 
-int actmi_finalize(actmi_handle h, void* stream) { return h ? engine_finalize(h, S(stream)) : ACTMI_E_INVALID; }
+int actmi_finalize(actmi_handle h, void* stream) {
+    if (!h) return ACTMI_E_INVALID;
+    ENTER(h);
+    return engine_finalize(h, S(stream));
+}
 
 int actmi_forward_infer(actmi_handle h, const float* qpos, const void* image, int image_fmt, int B, float* a_hat,
                         void* stream) {
     if (!h) return ACTMI_E_INVALID;
+    ENTER(h);
     if (!qpos || !image || !a_hat) return bad(h, "null pointer");
     return engine_forward_infer(h, qpos, image, image_fmt, B, a_hat, S(stream), nullptr);
 }
@@ -77,6 +104,7 @@ int actmi_forward_infer(actmi_handle h, const float* qpos, const void* image, in
 int actmi_forward_infer_vq(actmi_handle h, const float* qpos, const void* image, int image_fmt, int B,
                            const float* vq_sample, float* a_hat, void* stream) {
     if (!h) return ACTMI_E_INVALID;
+    ENTER(h);
     if (!qpos || !image || !a_hat || !vq_sample) return bad(h, "null pointer");
     if (!h->cfg.vq) return bad(h, "handle was not created with vq = 1");
     return engine_forward_infer(h, qpos, image, image_fmt, B, a_hat, S(stream), vq_sample);
@@ -86,18 +114,30 @@ int actmi_forward_train(actmi_handle h, const float* qpos, const void* image, in
                         const uint8_t* is_pad, const float* eps, uint64_t dropout_seed, float dropout_p, int B, float* losses,
                         float* a_hat, float* mu, float* logvar, void* stream) {
     if (!h) return ACTMI_E_INVALID;
+    ENTER(h);
     if (!qpos || !image || !actions || !is_pad) return bad(h, "null pointer");
     return train_forward(h, qpos, image, image_fmt, actions, is_pad, eps, dropout_seed, dropout_p, B, losses, a_hat, mu, logvar,
                          S(stream));
 }
-int actmi_backward(actmi_handle h, float loss_scale, void* stream) { return h ? train_backward(h, loss_scale, S(stream)) : ACTMI_E_INVALID; }
-int actmi_zero_grad(actmi_handle h, void* stream) { return h ? train_zero_grad(h, S(stream)) : ACTMI_E_INVALID; }
+int actmi_backward(actmi_handle h, float loss_scale, void* stream) {
+    if (!h) return ACTMI_E_INVALID;
+    ENTER(h);
+    return train_backward(h, loss_scale, S(stream));
+}
+int actmi_zero_grad(actmi_handle h, void* stream) {
+    if (!h) return ACTMI_E_INVALID;
+    ENTER(h);
+    return train_zero_grad(h, S(stream));
+}
 int actmi_adamw_step(actmi_handle h, float lr, float lr_backbone, float weight_decay, float beta1, float beta2, float eps,
                      int64_t step, void* stream) {
-    return h ? train_adamw_step(h, lr, lr_backbone, weight_decay, beta1, beta2, eps, step, S(stream)) : ACTMI_E_INVALID;
+    if (!h) return ACTMI_E_INVALID;
+    ENTER(h);
+    return train_adamw_step(h, lr, lr_backbone, weight_decay, beta1, beta2, eps, step, S(stream));
 }
 int actmi_grad_ptr(actmi_handle h, const char* key, void** dev_ptr, int64_t* numel) {
     if (!h || !key) return ACTMI_E_INVALID;
+    ENTER(h);
     if (!h->train) return bad(h, "handle was created without enable_training", ACTMI_E_STATE);
     auto it = h->index.find(key);
     if (it == h->index.end()) return bad(h, std::string("unknown state_dict key: ") + key);
@@ -109,6 +149,7 @@ int actmi_grad_ptr(actmi_handle h, const char* key, void** dev_ptr, int64_t* num
 
 int actmi_grad_arena(actmi_handle h, void** dev_ptr, int64_t* nfloats) {
     if (!h) return ACTMI_E_INVALID;
+    ENTER(h);
     if (!h->train) return bad(h, "handle was created without enable_training", ACTMI_E_STATE);
     if (dev_ptr) *dev_ptr = h->train->gbase;
     if (nfloats) *nfloats = h->ptotal;
@@ -209,6 +250,7 @@ const char* actmi_op_last_error(void) { return g_op_error.c_str(); }
 
 int actmi_set_gemm_prec(actmi_handle h, int prec) {
     if (!h) return ACTMI_E_INVALID;
+    ENTER(h);
     if (prec != ACTMI_PREC_F32 && prec != ACTMI_PREC_F16X3) { h->err = "prec must be ACTMI_PREC_F32 or ACTMI_PREC_F16X3"; return ACTMI_E_INVALID; }
     h->gemm_prec = prec;
     h->finalized = false;
@@ -223,6 +265,7 @@ int actmi_debug_stop_after(actmi_handle h, const char* stage) {
 
 int actmi_debug_tensor(actmi_handle h, const char* name, const float** dev_ptr, int64_t* numel) {
     if (!h || !name) return ACTMI_E_INVALID;
+    ENTER(h);
     auto it = h->dbg.find(name);
     if (it == h->dbg.end()) return bad(h, std::string("no debug tensor ") + name);
     if (dev_ptr) *dev_ptr = it->second.ptr;

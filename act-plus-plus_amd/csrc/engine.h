@@ -80,6 +80,7 @@ struct TrainState {
 
 struct actmi_ctx {
     actmi_config cfg;
+    int device = 0;                    // HIP device the handle was created on (all its memory lives there)
     std::string err;
     std::vector<Param> params;
     std::unordered_map<std::string, int> index;

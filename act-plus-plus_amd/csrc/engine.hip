@@ -284,6 +284,7 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
     }
     actmi_ctx* ctx = new actmi_ctx();
     ctx->cfg = g;
+    if (hipGetDevice(&ctx->device) != hipSuccess) { g_create_error = "hipGetDevice failed"; delete ctx; return ACTMI_E_LAUNCH; }
     ctx->ptotal = 0;
     build_spec(ctx);
     // geometry
@@ -312,7 +313,8 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
         if (const char* e2 = getenv("ACTMI_FWD_SPLITK_TARGET")) ctx->sk_target = atoi(e2);
         if (const char* e2 = getenv("ACTMI_FWD_SPLITK_MINNK")) ctx->sk_minnk = atoi(e2) > 0 ? atoi(e2) : 1;
         if (const char* e2 = getenv("ACTMI_FWD_SPLITK_MAXTILES")) ctx->sk_maxtiles = atoi(e2);
-        ctx->splitk_ws_floats = (int64_t)16 << 20;          // 64 MB: small-batch slices only (ctx_gemm checks the fit)
+        // slices of split contractions (ctx_gemm checks the fit); 256 MB covers 4-way splits of the B = 8 launches
+        ctx->splitk_ws_floats = (int64_t)(getenv("ACTMI_FWD_SPLITK_WS_MB") ? atoi(getenv("ACTMI_FWD_SPLITK_WS_MB")) : 256) << 18;
         if ((rc = dev_alloc(ctx, &ctx->splitk_ws, ctx->splitk_ws_floats))) return fail(rc);
     }
     resolve_layers(ctx);

@@ -864,8 +864,14 @@ int launch_cfg_b(const GemmArgs& a, hipStream_t st) {
     const int splitk = a.splitk > 1 ? a.splitk : 1;
     dim3 grid(tiles_m * tiles_n, 1, (a.groups > 0 ? a.groups : 1) * splitk);
     if (prof_enabled()) {
-        char nm[64];
-        snprintf(nm, sizeof(nm), "gemm_%s_kernel<%d,%d,%d,%d,%d,%d>", PREC ? "f16x3" : "f32", BM, BN, WM, WN, AMODE, BMODE);
+        char nm[128];
+        // ACTMI_PROF_SHAPES=1: one profile class per distinct launch shape (bench.py --shapes: the per-shape table)
+        static const bool by_shape = getenv("ACTMI_PROF_SHAPES") && getenv("ACTMI_PROF_SHAPES")[0] == '1';
+        if (by_shape)
+            snprintf(nm, sizeof(nm), "gemm_%s_kernel<%d,%d,%d,%d,%d,%d>[M=%d,N=%d,K=%d,g=%d,sk=%d,wgs=%d]", PREC ? "f16x3" : "f32",
+                     BM, BN, WM, WN, AMODE, BMODE, a.M, a.N, a.K, a.groups, splitk, tiles_m * tiles_n * a.groups * splitk);
+        else
+            snprintf(nm, sizeof(nm), "gemm_%s_kernel<%d,%d,%d,%d,%d,%d>", PREC ? "f16x3" : "f32", BM, BN, WM, WN, AMODE, BMODE);
         const double g = a.groups;
         double abytes;
         if (AMODE == A_CONV) abytes = (double)(a.M / (a.Ho * a.Wo)) * a.H * a.W * a.Cin;

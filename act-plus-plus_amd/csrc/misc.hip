@@ -53,7 +53,9 @@ __global__ __launch_bounds__(64) void ensemble_kernel(float* __restrict__ ring, 
                                                       const float* __restrict__ chunk, double k,
                                                       double* __restrict__ out, uint8_t* __restrict__ populated,
                                                       int Q, int A) {
-    extern __shared__ unsigned char s_pop[];   // Q flags, oldest first
+    // one wave per episode.  LDS: Q doubles (normalised weight of row j, 0 when the row is not populated)
+    extern __shared__ __attribute__((aligned(8))) unsigned char s_raw[];
+    double* s_w = reinterpret_cast<double*>(s_raw);
     const int e = blockIdx.x, lane = threadIdx.x;
     const int t = tcount[e];
     float* rg = ring + (int64_t)e * Q * Q * A;
@@ -61,35 +63,48 @@ __global__ __launch_bounds__(64) void ensemble_kernel(float* __restrict__ ring, 
     float* slot = rg + (int64_t)(t % Q) * Q * A;
     for (int i = lane; i < Q * A; i += 64) slot[i] = ch[i];
     __syncthreads();
-    for (int j = lane; j < Q; j += 64) {
+    // rows oldest first: j -> r = t-(Q-1)+j; populated = all A values non-zero (imitate_episodes.py:405-406);
+    // weight exp(-k*i) with i = rank of the row among the populated ones (:407-409)
+    int base = 0;
+    double wpart = 0.0;
+    for (int j0 = 0; j0 < Q; j0 += 64) {
+        const int j = j0 + lane;
         const int r = t - (Q - 1) + j;
         bool pop = false;
-        if (r >= 0) {
+        if (j < Q && r >= 0) {
             const float* row = rg + ((int64_t)(r % Q) * Q + (t - r)) * A;
             pop = true;
             for (int a = 0; a < A; ++a) pop = pop && (row[a] != 0.f);
         }
-        s_pop[j] = pop ? 1 : 0;
-        if (populated) populated[(int64_t)e * Q + j] = pop ? 1 : 0;
-    }
-    __syncthreads();
-    if (lane < A) {
-        int n = 0;
-        for (int j = 0; j < Q; ++j) n += s_pop[j];
-        double wsum = 0.0;
-        for (int i = 0; i < n; ++i) wsum += exp(-k * (double)i);
-        double acc = 0.0;
-        int i = 0;
-        for (int j = 0; j < Q; ++j) {
-            if (!s_pop[j]) continue;
-            const int r = t - (Q - 1) + j;
-            const double v = (double)rg[((int64_t)(r % Q) * Q + (t - r)) * A + lane];
-            acc += v * (exp(-k * (double)i) / wsum);
-            ++i;
+        const unsigned long long m = __ballot(pop);
+        const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
+        base += __popcll(m);
+        const double w = pop ? exp(-k * (double)idx) : 0.0;
+        if (j < Q) {
+            s_w[j] = w;
+            if (populated) populated[(int64_t)e * Q + j] = pop ? 1 : 0;
         }
-        out[(int64_t)e * A + lane] = acc;
+        wpart += w;
     }
+    // fixed-order butterfly: every lane ends with the same sum
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wpart += __shfl_xor(wpart, o);
     __syncthreads();
+    // lanes (a, g): action component a = lane % 16-or-A-slot, row class g; A <= 64
+    const int per = A <= 16 ? 16 : (A <= 32 ? 32 : 64);
+    const int a = lane % per, g = lane / per, ng = 64 / per;
+    double acc = 0.0;
+    if (a < A) {
+        for (int j = g; j < Q; j += ng) {
+            const double w = s_w[j];
+            if (w != 0.0) {
+                const int r = t - (Q - 1) + j;
+                acc += (double)rg[((int64_t)(r % Q) * Q + (t - r)) * A + a] * (w / wpart);
+            }
+        }
+    }
+    for (int o = per; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
+    if (lane < A) out[(int64_t)e * A + lane] = acc;
     if (lane == 0) tcount[e] = t + 1;
 }
 
@@ -403,6 +418,6 @@ int launch_ensemble(float* ring, int* tcount, const float* chunk, double k, doub
                     int Q, int A, hipStream_t st) {
     if (E <= 0) return 0;
     if (A > 64) return -2;
-    hipLaunchKernelGGL(ensemble_kernel, dim3(E), dim3(64), Q, st, ring, tcount, chunk, k, out, populated, Q, A);
+    hipLaunchKernelGGL(ensemble_kernel, dim3(E), dim3(64), Q * sizeof(double), st, ring, tcount, chunk, k, out, populated, Q, A);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

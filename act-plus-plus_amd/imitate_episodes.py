@@ -30,11 +30,12 @@ from actmi.sim_utils import compute_dict_mean, draw_episode_poses, set_seed, sha
 from actmi import dist_utils  # noqa: E402
 
 
-def make_policy(policy_class, policy_config):
-    """reference imitate_episodes.py:182-191 (ACT only on this path)."""
+def make_policy(policy_class, policy_config, device=None):
+    """reference imitate_episodes.py:182-191 (ACT only on this path).  ``device``: the GPU this process owns
+    (cuda:LOCAL_RANK under a one-process-per-GPU launcher); None = the process's current device."""
     if policy_class == "ACT":
         from policy import ACTPolicy
-        return ACTPolicy(policy_config)
+        return ACTPolicy(policy_config, device=device)
     raise NotImplementedError(f"policy_class {policy_class} is outside the accelerated path (SURVEY §2)")
 
 
@@ -91,12 +92,14 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
     max_timesteps = int(config["episode_len"])
     task_name = config["task_name"]
     temporal_agg = config["temporal_agg"]
-    rank, world, _ = dist_utils.init_from_env()
+    rank, world, local_rank = dist_utils.init_from_env()
     on_gpu = torch.cuda.is_available()
-    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    # one process per GPU: everything of this rank (engine arena, streams, frames, ensemble ring) lives on cuda:LOCAL_RANK
+    dev = torch.device("cuda", local_rank if world > 1 else torch.cuda.current_device()) if on_gpu else torch.device("cpu")
 
     if policy is None:
-        policy = make_policy(policy_class, dict(policy_config, training=False))     # inference-only handle: no grad buffers
+        # inference-only handle (no grad buffers), built on this rank's device
+        policy = make_policy(policy_class, dict(policy_config, training=False), device=str(dev))
         ckpt_path = os.path.join(ckpt_dir, ckpt_name)
         if os.path.isfile(ckpt_path):
             loading_status = policy.deserialize(torch.load(ckpt_path, weights_only=True))
@@ -143,7 +146,8 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
         ensemble_factory = lambda E: TemporalEnsemble(E, num_queries, action_dim, 0.01, dev)   # noqa: E731
     if env_factory is None:
         from actmi.envs import make_sim_env
-        env_factory = lambda pose, idx: make_sim_env(task_name, camera_names, pose, seed=idx)  # noqa: E731
+        env_factory = lambda pose, idx: make_sim_env(task_name, camera_names, pose, seed=idx,   # noqa: E731
+                                                     synthetic=True if config.get("synthetic_env") else None)
 
     # poses in the reference's draw order, then this rank's contiguous shard
     poses = draw_episode_poses(task_name, num_rollouts, seed=1000)
@@ -151,6 +155,16 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
     counts = [shard_range(num_rollouts, r, world)[1] - shard_range(num_rollouts, r, world)[0] for r in range(world)]
     if max_parallel is None:
         max_parallel = getattr(getattr(policy, "model", None), "max_batch", None) or (hi - lo) or 1
+    pdev = getattr(getattr(policy, "model", None), "device", None)
+    if on_gpu and pdev is not None and torch.device(pdev) != dev:
+        raise RuntimeError(f"rank {rank}: policy engine is on {pdev} but this rank's tensors are on {dev}")
+    # on-screen rendering and per-episode video dumps (imitate_episodes.py:284-287, 342-346, 516-517) need matplotlib / cv2
+    # windows and files per episode: outside the accelerated path -- refused or announced, never silently dropped
+    if config.get("onscreen_render"):
+        raise NotImplementedError("onscreen_render is not available on the batched MI355X eval path (episodes step in "
+                                  "lock-step on the GPU; there is no per-episode matplotlib window)")
+    if save_episode and verbose and rank == 0:
+        print("note: save_episode=True writes the result_*.txt summary only; per-episode videos are not produced here")
 
     local_results = []
     env_max_reward = None
@@ -233,7 +247,8 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
 def forward_pass(data, policy):
     """reference imitate_episodes.py:529-532."""
     image_data, qpos_data, action_data, is_pad = data
-    image_data, qpos_data, action_data, is_pad = image_data.cuda(), qpos_data.cuda(), action_data.cuda(), is_pad.cuda()
+    dev = getattr(getattr(policy, "model", None), "device", None) or "cuda"
+    image_data, qpos_data, action_data, is_pad = (t.to(dev, non_blocking=True) for t in (image_data, qpos_data, action_data, is_pad))
     return policy(qpos_data, image_data, action_data, is_pad)
 
 
@@ -246,8 +261,13 @@ def train_bc(train_dataloader, val_dataloader, config, log=None):
     policy_config = config["policy_config"]
     validate_every = config["validate_every"]
     save_every = config["save_every"]
-    set_seed(seed)
-    policy = make_policy(policy_class, policy_config)
+    # data parallel (one process per GPU under torch.distributed.run): every rank builds the same initial policy on its own
+    # device, draws ITS OWN batches and dropout masks (seed + rank), averages gradients over RCCL in loss.backward(); only
+    # rank 0 writes checkpoints
+    rank, world, local_rank = dist_utils.init_from_env()
+    set_seed(seed + rank)
+    dev = f"cuda:{local_rank}" if world > 1 else None
+    policy = make_policy(policy_class, dict(policy_config, seed=policy_config.get("seed", seed) * world + rank), device=dev)
     if config.get("resume_ckpt_path"):
         loading_status = policy.deserialize(torch.load(config["resume_ckpt_path"], weights_only=True))
         print(f'Resume policy from: {config["resume_ckpt_path"]}, Status: {loading_status}')
@@ -283,12 +303,14 @@ def train_bc(train_dataloader, val_dataloader, config, log=None):
         optimizer.step()
         if log:
             log({k: float(v) for k, v in forward_dict.items()}, step)
-        if step % save_every == 0:
+        if step % save_every == 0 and rank == 0:
             torch.save(policy.serialize(), os.path.join(ckpt_dir, f"policy_step_{step}_seed_{seed}.ckpt"))
-    torch.save(policy.serialize(), os.path.join(ckpt_dir, "policy_last.ckpt"))
     best_step, min_val_loss, best_state_dict = best_ckpt_info
-    torch.save(best_state_dict, os.path.join(ckpt_dir, f"policy_step_{best_step}_seed_{seed}.ckpt"))
-    print(f"Training finished:\nSeed {seed}, val loss {min_val_loss:.6f} at step {best_step}")
+    if rank == 0:
+        torch.save(policy.serialize(), os.path.join(ckpt_dir, "policy_last.ckpt"))
+        torch.save(best_state_dict, os.path.join(ckpt_dir, f"policy_step_{best_step}_seed_{seed}.ckpt"))
+        print(f"Training finished:\nSeed {seed}, val loss {min_val_loss:.6f} at step {best_step}")
+    dist_utils.barrier()                # checkpoints are on disk before any rank goes on to read them
     return best_ckpt_info
 
 
@@ -319,15 +341,17 @@ def build_config(args):
             "policy_class": args["policy_class"], "onscreen_render": args.get("onscreen_render", False),
             "policy_config": policy_config, "task_name": task_name, "seed": args["seed"],
             "temporal_agg": args["temporal_agg"], "camera_names": camera_names, "real_robot": False,
-            "load_pretrain": False}
+            "load_pretrain": False, "synthetic_env": bool(args.get("synthetic_env", False))}
 
 
 def main(args):
     set_seed(1)
     config = build_config(args)
+    rank, world, _ = dist_utils.init_from_env()          # one process per GPU when a launcher set WORLD_SIZE
     os.makedirs(config["ckpt_dir"], exist_ok=True)
-    with open(os.path.join(config["ckpt_dir"], "config.pkl"), "wb") as f:
-        pickle.dump(config, f)
+    if rank == 0:
+        with open(os.path.join(config["ckpt_dir"], "config.pkl"), "wb") as f:
+            pickle.dump(config, f)
     if args["eval"]:
         results = []
         for ckpt_name in ["policy_last.ckpt"]:
@@ -353,14 +377,17 @@ def main(args):
                                                sample_weights=task_config.get("sample_weights"),
                                                train_ratio=task_config.get("train_ratio", 0.99))
     else:
-        train_dl = SyntheticDataset(cfg, args["batch_size"], 8, seed=args["seed"])
-        val_dl = SyntheticDataset(cfg, args["batch_size"], 2, seed=args["seed"] + 1)
+        train_dl = SyntheticDataset(cfg, args["batch_size"], 8, seed=args["seed"] * world + rank)     # disjoint per rank
+        val_dl = SyntheticDataset(cfg, args["batch_size"], 2, seed=args["seed"] * world + rank + 100003)
         stats = _default_stats(14)
-    with open(os.path.join(config["ckpt_dir"], "dataset_stats.pkl"), "wb") as f:
-        pickle.dump(stats, f)
+    if rank == 0:
+        with open(os.path.join(config["ckpt_dir"], "dataset_stats.pkl"), "wb") as f:
+            pickle.dump(stats, f)
     best_step, min_val_loss, best_state_dict = train_bc(train_dl, val_dl, config)
-    torch.save(best_state_dict, os.path.join(config["ckpt_dir"], "policy_best.ckpt"))
-    print(f"Best ckpt, val loss {min_val_loss:.6f} @ step{best_step}")
+    if rank == 0:
+        torch.save(best_state_dict, os.path.join(config["ckpt_dir"], "policy_best.ckpt"))
+        print(f"Best ckpt, val loss {min_val_loss:.6f} @ step{best_step}")
+    dist_utils.barrier()
 
 
 if __name__ == "__main__":
@@ -392,6 +419,9 @@ if __name__ == "__main__":
     # additions (rollouts count hard-coded to 10 in the reference, :156)
     parser.add_argument("--num_rollouts", action="store", type=int, default=50)
     parser.add_argument("--max_batch", action="store", type=int, default=None)
+    parser.add_argument("--synthetic_env", action="store_true",
+                        help="evaluate on the SyntheticEnv stand-in even when a sim_env module is importable "
+                             "(throughput / plumbing runs; its success rates are not task results)")
     parser.add_argument("--dataset_dir", action="store", type=str, default=None,
                         help="episode files (reference HDF5 layout, or .npz with the same keys); default: the task's dataset_dir")
     main(vars(parser.parse_args()))

@@ -59,7 +59,7 @@ class _AdamW:
 class ACTPolicy:
     """reference policy.py:243-348."""
 
-    def __init__(self, args_override: dict, max_batch: int = None, device: str = "cuda:0", init_seed: int = 0):
+    def __init__(self, args_override: dict, max_batch: int = None, device: str = None, init_seed: int = 0):
         # reference policy.py:247-249: use_depth / use_pcd default False (the fork's depth_camera_names lookup
         # raises KeyError with the stock config, SURVEY §2.1; the intent is "absent")
         self.use_depth = args_override.get("use_depth", False)
@@ -71,6 +71,10 @@ class ACTPolicy:
         self.kl_weight = args_override["kl_weight"]
         self.vq = args_override.get("vq", False)
         mb = max_batch or int(args_override.get("max_batch", 8))
+        # device: explicit argument, else policy_config["device"], else THIS process's current device (one process per
+        # GPU: dist_utils.init_from_env has made cuda:LOCAL_RANK current) -- never a hard-coded cuda:0
+        if device is None:
+            device = args_override.get("device") or (f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cuda:0")
         self.model = ACTEngine(self.cfg, max_batch=mb, device=device, training=bool(args_override.get("training", True)))
         # random init of the reference architecture (the ImageNet fetch of backbone.py:121-124 cannot run offline)
         from actmi.weights import generate_state_dict
