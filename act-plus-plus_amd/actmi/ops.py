@@ -88,6 +88,85 @@ def gemm(A, W, bias=None, scale=None, res=None, res_mod=0, relu=False, a_add=Non
     return out
 
 
+def split16v2(x, scale=1.0):
+    """"s16" form of an f32 cuda tensor whose last dimension is a multiple of 8 (gemm16 operands): same shape / strides, every
+    aligned group of 8 floats replaced by [8 fp16 hi][8 fp16 lo] of (x * scale).  Returned as an f32-typed tensor of raw bits."""
+    lib = L.load()
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    L.check(lib.actmi_op_split16v2(_p(x), _p(out), x.numel(), float(scale), L.current_stream_ptr()), None, "op_split16v2")
+    return out
+
+
+def unsplit16v2(x16, scale=1.0):
+    """inverse of split16v2: (hi + lo) / scale."""
+    lib = L.load()
+    out = torch.empty_like(x16)
+    L.check(lib.actmi_op_unsplit16v2(_p(x16), _p(out), x16.numel(), float(scale), L.current_stream_ptr()), None,
+            "op_unsplit16v2")
+    return out
+
+
+_ZERO_PAGE = {}
+
+
+def _zero_page(dev):
+    if dev not in _ZERO_PAGE:
+        _ZERO_PAGE[dev] = torch.zeros(64, dtype=torch.float32, device=dev)
+    return _ZERO_PAGE[dev]
+
+
+def gemm16(A16, W16, alpha=1.0, bias=None, scale=None, res=None, res_fmt="s16", res_mod=0, res_scale=1.0, relu=False,
+           out_fmt="s16", out_scale=1.0, rowmap=None, out_rows=None, bm=0, splitk=0, conv=None, flag=None, out=None):
+    """Forward GEMM on pre-split operands.  A16 [M,K] (or, with conv=dict(stride, pad, KH, KW), NHWC images [G,B,H,W,Cin]),
+    W16 [N,K] (conv: [G,Cout,KH,KW,Cin]), both from split16v2; alpha = 1 / (scale of A * scale of W).
+    Returns an s16 tensor holding (value * out_scale) or, with out_fmt="f32", plain floats.  splitk > 1 returns the f32 slices
+    [splitk, M, N] (sum them to get the product * alpha)."""
+    lib = L.load()
+    d = L.Gemm16Desc()
+    if conv is not None:
+        G, B, H, W, Cin = A16.shape
+        _, Cout, KH, KW, _ = W16.shape
+        stride, pad = conv["stride"], conv["pad"]
+        Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        M, N, K = B * Ho * Wo, Cout, KH * KW * Cin
+        d.mode = 1
+        d.H, d.W, d.Cin, d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo = H, W, Cin, KH, KW, stride, pad, Ho, Wo
+        d.img_stride, d.lda = H * W * Cin, Cin
+        d.groups, d.gA, d.gB, d.gSB = G, B * H * W * Cin, Cout * K, Cout
+        d.gC = d.gRes = M * N
+        d.zero_page = _zero_page(A16.device).data_ptr()
+        oshape = (G, B, Ho, Wo, Cout)
+        ldc = N
+    else:
+        M, K = A16.shape
+        N = W16.shape[0]
+        d.mode, d.lda, d.groups = 0, A16.stride(0), 1
+        oshape = (out_rows or M, N)
+        ldc = N
+    d.A, d.Bw, d.ldb = A16.data_ptr(), W16.data_ptr(), K
+    d.alpha = float(alpha)
+    d.scale = scale.data_ptr() if scale is not None else None
+    d.bias = bias.data_ptr() if bias is not None else None
+    if res is not None:
+        d.res, d.ldres, d.res_fmt, d.res_mod, d.res_scale = res.data_ptr(), N, 1 if res_fmt == "s16" else 0, res_mod, res_scale
+    d.relu = 1 if relu else 0
+    d.M, d.N, d.K = M, N, K
+    d.bm = bm
+    d.flag = flag.data_ptr() if flag is not None else None
+    if splitk and splitk > 1:
+        out = torch.empty((splitk,) + tuple(oshape), dtype=torch.float32, device=A16.device)
+        d.splitk, d.split_stride, d.c_fmt = int(splitk), (d.groups * M * N), 0
+    else:
+        if out is None:
+            out = torch.zeros(oshape, dtype=torch.float32, device=A16.device)
+        d.c_fmt, d.c_scale = (1 if out_fmt == "s16" else 0), float(out_scale)
+        d.rowmap = rowmap.data_ptr() if rowmap is not None else None
+    d.C, d.ldc = out.data_ptr(), ldc
+    L.check(lib.actmi_op_gemm16(C.byref(d), L.current_stream_ptr()), None, "op_gemm16")
+    return out
+
+
 def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1, pad=1, prec=None, w_split=False):
     """x [G,B,H,W,Cin] camera-major NHWC; w_ohwi [G,Cout,KH,KW,Cin]; scale/bias [G,Cout]; returns [G,B,Ho,Wo,Cout]."""
     lib = L.load()

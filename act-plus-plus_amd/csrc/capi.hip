@@ -175,6 +175,26 @@ int actmi_op_split16(const float* src, float* dst, int64_t nfloats, float scale,
     return rc == 0 ? 0 : ACTMI_E_INVALID;
 }
 
+int actmi_op_split16v2(const float* src, void* dst, int64_t nfloats, float scale, void* stream) {
+    g_op_error.clear();
+    const int rc = launch_split16v2(src, dst, nfloats, scale, S(stream));
+    if (rc != 0) g_op_error = "split16v2: nfloats must be a multiple of 8 and both pointers 16-byte aligned";
+    return rc == 0 ? 0 : ACTMI_E_INVALID;
+}
+
+int actmi_op_unsplit16v2(const void* src, float* dst, int64_t nfloats, float scale, void* stream) {
+    g_op_error.clear();
+    const int rc = launch_unsplit16v2(src, dst, nfloats, scale, S(stream));
+    if (rc != 0) g_op_error = "unsplit16v2: nfloats must be a multiple of 8, pointers 16-byte aligned, scale > 0";
+    return rc == 0 ? 0 : ACTMI_E_INVALID;
+}
+
+int actmi_op_gemm16(const actmi_gemm16_desc* d, void* stream) {
+    if (!d) return ACTMI_E_INVALID;
+    g_op_error.clear();
+    return launch_gemm16(*d, S(stream), &g_op_error);
+}
+
 int actmi_op_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, void* stream) {
     g_op_error.clear();
     return launch_pow2_scale(x, ld, M, N, out, S(stream)) == 0 ? 0 : ACTMI_E_LAUNCH;

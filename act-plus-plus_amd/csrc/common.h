@@ -39,6 +39,13 @@ struct SplitCombineArgs {
 };
 int launch_splitk_combine(const SplitCombineArgs& a, hipStream_t st);
 
+// ---- forward GEMM / implicit-GEMM convolution on pre-split ("s16") operands (gemm16.hip): descriptor is part of the C ABI
+typedef actmi_gemm16_desc Gemm16Args;
+int launch_gemm16(const Gemm16Args& a, hipStream_t st, std::string* err);
+int gemm16_pick_bm(int M, int N, int groups, int splitk);
+int launch_split16v2(const float* src, void* dst, int64_t nfloats, float scale, hipStream_t st);
+int launch_unsplit16v2(const void* src, float* dst, int64_t nfloats, float scale, hipStream_t st);
+
 // ---- conv1 7x7/s2 + FrozenBN + ReLU (conv1.hip) -----------------------------------------------
 struct Conv1Args {
     const void* image;    // u8 NHWC [B][C][H][W][3] or f32 NCHW [B][C][3][H][W]

@@ -134,6 +134,44 @@ typedef struct actmi_gemm_desc {
     int64_t split_stride;
 } actmi_gemm_desc;
 
+/* GEMM / implicit-GEMM convolution on PRE-SPLIT operands (the inference path's form of actmi_gemm_desc with prec f16x3;
+ * same reference call sites: nn.Linear / MHA projections transformer.py:196-224, input_proj detr_vae.py:184, torchvision
+ * Conv2d + FrozenBatchNorm2d backbone.py:47-57).  "s16" tensors hold, for every aligned group of 8 consecutive elements
+ * of a row, 32 bytes = [8 fp16 hi pieces][8 fp16 lo pieces] of (x * tensor scale): the byte size, strides and addressing
+ * are those of the fp32 tensor (all ld / group strides below are in ELEMENTS, 4 bytes each), see actmi_op_split16v2.
+ * C[rowmap(m)][n] = act((sum_k A[m][k] * Bw[n][k]) * alpha * scale[n] + bias[n] + residual[m or m % res_mod][n]) */
+typedef struct actmi_gemm16_desc {
+    const void* A;             /* s16: rows [M][K] (mode 0) or NHWC images [img][H][W][Cin] (mode 1) */
+    int64_t lda;
+    int32_t mode;              /* 0 rows, 1 NHWC implicit im2col (K index = (r*KW+s)*Cin + c, Cin % 32 == 0) */
+    int32_t H, W, Cin, KH, KW, stride, pad, Ho, Wo;
+    int64_t img_stride;
+    const void* Bw;            /* s16 [N][K] (torch Linear layout / [cout][(r,s,c)]) */
+    int64_t ldb;
+    float alpha;               /* undoes the operand scales: 1 / (scale of A * scale of Bw); 0 means 1 */
+    const float* scale;        /* per-n or NULL (FrozenBN) */
+    const float* bias;         /* per-n or NULL */
+    const void* res;           /* residual or NULL */
+    int64_t ldres;
+    int32_t res_fmt;           /* 0: f32 rows, 1: s16 rows (value = (hi + lo) * res_scale) */
+    int32_t res_mod;           /* >0: residual row = m % res_mod (a table shared by the batch) */
+    float res_scale;           /* 1 / (scale of the s16 residual); 0 means 1 */
+    int32_t relu;
+    void* C;
+    int64_t ldc;
+    int32_t c_fmt;             /* 0: f32 rows, 1: s16 rows of (value * c_scale) */
+    float c_scale;             /* 0 means 1 */
+    const int32_t* rowmap;     /* optional scatter of output rows */
+    int32_t M, N, K;           /* K % 32 == 0, N % 8 == 0 */
+    int32_t groups;
+    int64_t gA, gB, gSB, gC, gRes;
+    int32_t splitk;            /* >1: contraction split over the grid into plain f32 slices at C + s*split_stride */
+    int64_t split_stride;
+    const void* zero_page;     /* mode 1: >= 128 bytes of zeros (padding taps read it) */
+    uint32_t* flag;            /* optional: bit 0 is set when an s16 output value is not finite or leaves the fp16 range */
+    int32_t bm;                /* tile rows: 0 = choose, 128 or 256 */
+} actmi_gemm16_desc;
+
 /* Multi-head attention descriptor: softmax(scale * q k^T [+ key padding mask]) v per (batch, head).
  * Replaces nn.MultiheadAttention's bmm/softmax/bmm (transformer.py:217-218, 282-289). */
 typedef struct actmi_attn_desc {
@@ -213,6 +251,12 @@ int actmi_op_gemm(const actmi_gemm_desc* d, void* stream);
  * alias).  scale must be a power of two with |src| * scale < 65504; 256 suits network weights: pieces of values
  * around 1e-2 then stay normal fp16 numbers (full 22-bit split) instead of subnormals. */
 int actmi_op_split16(const float* src, float* dst, int64_t nfloats, float scale, void* stream);
+/* s16 form of a row-major f32 tensor (actmi_gemm16_desc): dst = split of (src * scale), nfloats % 8 == 0, device pointers
+ * that may not alias; scale a power of two with |src| * scale < 65504.  actmi_op_unsplit16v2 is the inverse
+ * (dst = (hi + lo) / scale: exact to the 22-23 significand bits the split keeps). */
+int actmi_op_split16v2(const float* src, void* dst, int64_t nfloats, float scale, void* stream);
+int actmi_op_unsplit16v2(const void* src, float* dst, int64_t nfloats, float scale, void* stream);
+int actmi_op_gemm16(const actmi_gemm16_desc* d, void* stream);
 /* out[0] = the power of two s with max|x| * s in [2^13, 2^14) over the M x N matrix x (row stride ld); 1 if x is all
  * zero or not finite.  out[1] is scratch and must be zero before the first use (the op leaves it zero).  For actmi_gemm_desc.a_scale_dev / b_scale_dev. */
 int actmi_op_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, void* stream);
