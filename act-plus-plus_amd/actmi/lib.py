@@ -62,7 +62,7 @@ class Gemm16Desc(C.Structure):
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("groups", C.c_int32),
         ("gA", C.c_int64), ("gB", C.c_int64), ("gSB", C.c_int64), ("gC", C.c_int64), ("gRes", C.c_int64),
         ("splitk", C.c_int32), ("split_stride", C.c_int64),
-        ("zero_page", C.c_void_p), ("flag", C.c_void_p), ("bm", C.c_int32),
+        ("zero_page", C.c_void_p), ("flag", C.c_void_p), ("bm", C.c_int32), ("stamps", C.c_void_p),
     ]
 
 

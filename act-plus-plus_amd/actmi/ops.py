@@ -117,7 +117,8 @@ def _zero_page(dev):
 
 
 def gemm16(A16, W16, alpha=1.0, bias=None, scale=None, res=None, res_fmt="s16", res_mod=0, res_scale=1.0, relu=False,
-           out_fmt="s16", out_scale=1.0, rowmap=None, out_rows=None, bm=0, splitk=0, conv=None, flag=None, out=None):
+           out_fmt="s16", out_scale=1.0, rowmap=None, out_rows=None, bm=0, splitk=0, conv=None, flag=None, out=None,
+           _ld_override=None, stamps=None):
     """Forward GEMM on pre-split operands.  A16 [M,K] (or, with conv=dict(stride, pad, KH, KW), NHWC images [G,B,H,W,Cin]),
     W16 [N,K] (conv: [G,Cout,KH,KW,Cin]), both from split16v2; alpha = 1 / (scale of A * scale of W).
     Returns an s16 tensor holding (value * out_scale) or, with out_fmt="f32", plain floats.  splitk > 1 returns the f32 slices
@@ -145,6 +146,8 @@ def gemm16(A16, W16, alpha=1.0, bias=None, scale=None, res=None, res_fmt="s16", 
         oshape = (out_rows or M, N)
         ldc = N
     d.A, d.Bw, d.ldb = A16.data_ptr(), W16.data_ptr(), K
+    if _ld_override is not None:           # diagnostics: (lda, ldb) e.g. (0, 0) makes every row the same cache-resident line
+        d.lda, d.ldb = _ld_override
     d.alpha = float(alpha)
     d.scale = scale.data_ptr() if scale is not None else None
     d.bias = bias.data_ptr() if bias is not None else None
@@ -154,6 +157,7 @@ def gemm16(A16, W16, alpha=1.0, bias=None, scale=None, res=None, res_fmt="s16", 
     d.M, d.N, d.K = M, N, K
     d.bm = bm
     d.flag = flag.data_ptr() if flag is not None else None
+    d.stamps = stamps.data_ptr() if stamps is not None else None
     if splitk and splitk > 1:
         out = torch.empty((splitk,) + tuple(oshape), dtype=torch.float32, device=A16.device)
         d.splitk, d.split_stride, d.c_fmt = int(splitk), (d.groups * M * N), 0

@@ -170,6 +170,9 @@ typedef struct actmi_gemm16_desc {
     const void* zero_page;     /* mode 1: >= 128 bytes of zeros (padding taps read it) */
     uint32_t* flag;            /* optional: bit 0 is set when an s16 output value is not finite or leaves the fp16 range */
     int32_t bm;                /* tile rows: 0 = choose, 128 or 256 */
+    /* diagnostic, never set on the product path: thread 0 of workgroup 0 writes shader-clock stamps (s_memtime) here:
+     * [0] entry, [1] first step landed, then per tile [2+2i] K loop done, [3+2i] epilogue done; [63] = s_memrealtime span */
+    uint64_t* stamps;
 } actmi_gemm16_desc;
 
 /* Multi-head attention descriptor: softmax(scale * q k^T [+ key padding mask]) v per (batch, head).

@@ -23,7 +23,8 @@ def test_split16v2_round_trip_and_layout():
     x = torch.randn(512, 64, generator=g) * torch.logspace(-3, 3, 512).unsqueeze(1)
     s = ops.split16v2(x.to(D), 4.0)
     back = ops.unsplit16v2(s, 4.0).cpu()
-    assert float(((back - x).abs() / x.abs().clamp_min(1e-30)).max()) < 2.0 ** -21
+    # 2^-22 relative (two 11-bit pieces); values whose lo piece is an fp16 subnormal keep an absolute floor of 2^-25 / scale
+    assert bool(((back - x).abs() <= x.abs() * 2.0 ** -21 + 2.0 ** -25 / 4.0).all())
     halves = s.cpu().view(torch.float16).view(-1, 16).double()                  # per group of 8: hi0..7, lo0..7
     xs = (x.double() * 4.0).view(-1, 8)
     hi = xs.float().half()                                                       # rn16
