@@ -229,8 +229,18 @@ class ACTEngine:
         qpos = qpos.to(torch.float32).contiguous()
         image = image.contiguous()
         fmt = self._image_fmt(image, B)
-        actions = actions[:, :Q].to(torch.float32).contiguous()          # policy.py:289-290
-        is_pad_u8 = is_pad[:, :Q].to(torch.uint8).contiguous()
+        actions = actions[:, :Q].to(torch.float32)                        # policy.py:289-290
+        is_pad_u8 = is_pad[:, :Q].to(torch.uint8)
+        if tuple(actions.shape[:2]) != tuple(is_pad_u8.shape[:2]) or actions.shape[0] != B or actions.shape[-1] != A:
+            raise ValueError(f"actions {tuple(actions.shape)} / is_pad {tuple(is_pad_u8.shape)} do not match [B={B}, T, A={A}]")
+        if actions.shape[1] < Q:
+            # episodes shorter than the chunk (the reference's padded_action is max_episode_len long, utils.py:120-133, and
+            # its l1 loss would fail on the shape): continue the dataset's own padding -- zero actions, is_pad = True -- up to
+            # the Q steps the library reads (it used to read past the end of the shorter tensors)
+            T_ = actions.shape[1]
+            actions = torch.cat([actions, actions.new_zeros((B, Q - T_, A))], dim=1)
+            is_pad_u8 = torch.cat([is_pad_u8, is_pad_u8.new_ones((B, Q - T_))], dim=1)
+        actions, is_pad_u8 = actions.contiguous(), is_pad_u8.contiguous()
         dev = qpos.device
         if cfg.vq:
             eps = None if vq_code is None else vq_code.to(device=dev, dtype=torch.float32).reshape(B, Lz).contiguous()
@@ -248,6 +258,12 @@ class ACTEngine:
             C.c_void_p(is_pad_u8.data_ptr()), C.c_void_p(eps.data_ptr() if eps is not None else 0), C.c_uint64(dropout_seed),
             float(dropout_p), B, C.c_void_p(losses.data_ptr()), C.c_void_p(a_hat.data_ptr()), C.c_void_p(mu.data_ptr()),
             C.c_void_p(logvar.data_ptr()), self._sp()), self.h, "forward_train")
+        self._last_losses = losses
+        if os.environ.get("ACTMI_DEBUG_LOSS") == "1" and not bool(torch.isfinite(losses).all()):
+            print("[actmi debug] non-finite losses", losses.tolist(), "B", B, "a_hat finite", bool(torch.isfinite(a_hat).all()),
+                  "mu finite", bool(torch.isfinite(mu).all()), "logvar finite", bool(torch.isfinite(logvar).all()),
+                  "logvar max", float(logvar.max()), "dropout", dropout_p, "actions finite", bool(torch.isfinite(actions).all()),
+                  "qpos finite", bool(torch.isfinite(qpos).all()), "is_pad sum", is_pad_u8.sum(1).tolist(), flush=True)
         out = {"l1": losses[0], "kl": losses[1], "loss": losses[2], "a_hat": a_hat}
         if cfg.vq:
             probs, binaries = mu.view(B, cfg.vq_class, cfg.vq_dim), logvar.view(B, cfg.vq_class, cfg.vq_dim)
@@ -286,6 +302,30 @@ class ACTEngine:
         L.check(self.lib.actmi_grad_ptr(self.h, key.encode(), C.byref(p), C.byref(n)), self.h, f"grad_ptr({key})")
         torch.cuda.synchronize(self.device)
         return _from_ptr(p.value, n.value, self.device).clone().view(self.spec[key])
+
+    # ---- range / finiteness guard -----------------------------------------------------------------
+    FLAG_OUTPUT, FLAG_WEIGHT, FLAG_LOSS = 1, 2, 4
+
+    def read_flags(self, clear: bool = True) -> int:
+        """The handle's device flag word (synchronises the current stream: call where the host waits anyway, e.g. right
+        after the actions of a step were copied to the host)."""
+        f = C.c_uint32(0)
+        L.check(self.lib.actmi_get_flags(self.h, C.byref(f), 1 if clear else 0, self._sp()), self.h, "get_flags")
+        return int(f.value)
+
+    def check_flags(self):
+        """Raise FloatingPointError when a kernel of this handle reported a non-finite output / loss or a weight beyond the
+        range of its split image since the last check (default-on guard of the f16x3 arithmetic)."""
+        f = self.read_flags(clear=True)
+        if f:
+            what = [n for b, n in ((1, "an inference output was not finite (an operand left the fp16-split range |x| < 65504)"),
+                                   (2, "a weight has outgrown the scale of its split image: call finalize() again"),
+                                   (4, "a training loss was not finite")) if f & b]
+            last = getattr(self, "_last_losses", None)
+            if f & 4 and last is not None:
+                what.append(f"last [l1, kl, loss] = {last.tolist()}")
+            raise FloatingPointError("libactmi range guard: " + "; ".join(what) + " -- gemm_prec='f32' (ACTMI_GEMM_PREC=f32) "
+                                     "runs the same step on the native fp32 MFMA")
 
     # ---- debug --------------------------------------------------------------------------------
     def debug_stop_after(self, stage: str):

@@ -277,6 +277,16 @@ int actmi_set_gemm_prec(actmi_handle h, int prec) {
     return 0;
 }
 
+int actmi_get_flags(actmi_handle h, uint32_t* host_flags, int clear, void* stream) {
+    if (!h || !host_flags) return ACTMI_E_INVALID;
+    ENTER(h);
+    hipError_t e = hipMemcpyAsync(host_flags, h->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, S(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
+    if (e == hipSuccess && clear && *host_flags) e = hipMemsetAsync(h->flags, 0, sizeof(uint32_t), S(stream));
+    if (e != hipSuccess) return bad(h, std::string("get_flags: ") + hipGetErrorString(e), ACTMI_E_LAUNCH);
+    return 0;
+}
+
 int actmi_debug_stop_after(actmi_handle h, const char* stage) {
     if (!h) return ACTMI_E_INVALID;
     h->stop_stage = stage ? stage : "";

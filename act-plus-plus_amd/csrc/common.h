@@ -60,9 +60,10 @@ struct Conv1Args {
     const unsigned char* wimg = nullptr;   // f16x3 only, optional: launch_conv1_wimg's image of w (C x conv1_wimg_bytes())
     int vpool = 0;        // f16x3 only: write max over conv rows (2a-1, 2a, 2a+1) -> out [C][B][Ho/2][Wo][Cout] (pool's vertical half)
     int vpool_nseg = 1;   // set by the launcher
+    float wscale = 256.f; // f16x3 only: power of two the split weight image was built with (undone in the epilogue)
 };
 int64_t conv1_wimg_bytes();
-int launch_conv1_wimg(const float* w, void* img, int C, int Cout, hipStream_t st);
+int launch_conv1_wimg(const float* w, void* img, int C, int Cout, hipStream_t st, float wscale = 256.f);
 int launch_conv1(const Conv1Args& a, hipStream_t st, std::string* err);
 
 // ---- direct 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels, f16x3 (conv3.hip) ----------
@@ -154,7 +155,13 @@ int launch_cvae_maps(int* map, uint8_t* kpm, const uint8_t* is_pad, int B, int Q
 int launch_axpy(float* dst, const float* src, int64_t n, hipStream_t st);
 int launch_scale(float* x, int64_t n, float s, hipStream_t st);
 int launch_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, hipStream_t st);
-int launch_split16(const float* src, float* dst, int64_t nfloats, float scale, hipStream_t st);
+int launch_split16(const float* src, float* dst, int64_t nfloats, float scale, hipStream_t st, uint32_t* flag = nullptr);
+// range guard of the f16x3 weight images (misc.hip): per-segment max |x| (as float bits), the parameter arena split with one
+// power-of-two scale per parameter, and the finite check of an output
+int launch_seg_amax(const float* base, const int64_t* off, const int64_t* numel, int nseg, unsigned* out_bits, hipStream_t st);
+int launch_split16_map(const float* src, float* dst, int64_t nfloats, const int* seg_of_group64, const float* seg_scale,
+                       uint32_t* flag, hipStream_t st);
+int launch_check_finite(const float* x, int64_t n, uint32_t* flag, uint32_t bit, hipStream_t st);
 int launch_dropout_bwd(const float* dy, float* dz, uint64_t seed, float p, int64_t n, hipStream_t st);
 int launch_attn_drop(const float* P, float* Pd, uint64_t seed, float p, int G, int Nq, int Nk, int ldp, hipStream_t st);
 int launch_attn_ds_drop(const float* P, float* dP, const float* delta, float scale, uint64_t seed, float p, int G, int Nq,

@@ -222,7 +222,7 @@ constexpr int F_NG = 22;                                           // contractio
 constexpr int F_WROW = 368;                                        // bytes per channel row of one weight piece
 constexpr int F_WBYTES = 64 * F_WROW;
 constexpr int F_SMEM = 2 * F_WBYTES + 2 * F_PATCH + 3 * 256 * 4;
-constexpr float F_WSCALE = 256.f;
+constexpr float F_WSCALE = 256.f;      // default of Conv1Args::wscale
 
 // 4x4 transpose across a quad of lanes: before, lane j of the quad holds (r0..r3) = row j; after, lane k holds column k
 // as (r0..r3) = (row0[k], row1[k], row2[k], row3[k]).  Two exchange stages on DPP quad permutes (no LDS traffic).
@@ -249,24 +249,24 @@ __device__ __forceinline__ uint32_t split1(float v) {              // (hi | lo <
 }
 
 // one entry of the weight image: element e = (n, group gi = r*3+g, j) -> (hi, lo) halfs of w[n][r*21 + 8g + j] * 2^8
-__device__ __forceinline__ void conv1_wimg_entry(const float* wg, int Cout, int e, uint16_t& h, uint16_t& l) {
+__device__ __forceinline__ void conv1_wimg_entry(const float* wg, int Cout, int e, float wscale, uint16_t& h, uint16_t& l) {
     const int n = e / (F_NG * 8), rem = e - n * (F_NG * 8);
     const int gi = rem >> 3, j = rem & 7;
     const int r = gi / 3, g = gi - r * 3, x = 8 * g + j;
     float v = 0.f;
-    if (n < Cout && gi < 21 && x < 21) v = wg[n * KPAD + r * 21 + x] * F_WSCALE;
+    if (n < Cout && gi < 21 && x < 21) v = wg[n * KPAD + r * 21 + x] * wscale;
     const uint32_t hl = split1(v);
     h = (uint16_t)(hl & 0xffffu);
     l = (uint16_t)(hl >> 16);
 }
 
 // the LDS weight image of conv1_f16x3_kernel for every camera: [cam][hi piece | lo piece], F_WBYTES each
-__global__ __launch_bounds__(256) void conv1_wimg_kernel(const float* __restrict__ w, unsigned char* __restrict__ img, int Cout) {
+__global__ __launch_bounds__(256) void conv1_wimg_kernel(const float* __restrict__ w, unsigned char* __restrict__ img, int Cout, float wscale) {
     const int cam = blockIdx.y;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= 64 * F_NG * 8) return;
     uint16_t h, l;
-    conv1_wimg_entry(w + (int64_t)cam * Cout * KPAD, Cout, e, h, l);
+    conv1_wimg_entry(w + (int64_t)cam * Cout * KPAD, Cout, e, wscale, h, l);
     const int n = e / (F_NG * 8), rem = e - n * (F_NG * 8);
     unsigned char* dst = img + (int64_t)cam * 2 * F_WBYTES;
     *reinterpret_cast<uint16_t*>(dst + n * F_WROW + rem * 2) = h;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void conv1_f16x3_kernel(Conv1Args p, int tiles
         const float* wg = p.w + (int64_t)cam * p.Cout * KPAD;
         for (int e = t; e < 64 * F_NG * 8; e += 256) {
             uint16_t h, l;
-            conv1_wimg_entry(wg, p.Cout, e, h, l);
+            conv1_wimg_entry(wg, p.Cout, e, p.wscale, h, l);
             const int n = e / (F_NG * 8), rem = e - n * (F_NG * 8);
             *reinterpret_cast<uint16_t*>(s_wh + n * F_WROW + rem * 2) = h;
             *reinterpret_cast<uint16_t*>(s_wl + n * F_WROW + rem * 2) = l;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void conv1_f16x3_kernel(Conv1Args p, int tiles
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int n = nt * 32 + li;
-        sc[nt] = (n < p.Cout) ? p.scale[cam * p.Cout + n] * (1.f / F_WSCALE) : 0.f;
+        sc[nt] = (n < p.Cout) ? p.scale[cam * p.Cout + n] * (1.f / p.wscale) : 0.f;
         bi[nt] = (n < p.Cout) ? p.bias[cam * p.Cout + n] : 0.f;
     }
 
@@ -563,11 +563,11 @@ __global__ __launch_bounds__(256) void conv1_f16x3_kernel(Conv1Args p, int tiles
 
 int64_t conv1_wimg_bytes() { return 2 * F_WBYTES; }
 
-int launch_conv1_wimg(const float* w, void* img, int C, int Cout, hipStream_t st) {
+int launch_conv1_wimg(const float* w, void* img, int C, int Cout, hipStream_t st, float wscale) {
     // the pad bytes of each row (22 groups x 16 B = 352 of 368) are never read; zeroed so that the image is deterministic
     if (hipMemsetAsync(img, 0, (size_t)C * 2 * F_WBYTES, st) != hipSuccess) return -3;
     hipLaunchKernelGGL(conv1_wimg_kernel, dim3((64 * F_NG * 8 + 255) / 256, C), dim3(256), 0, st, w,
-                       reinterpret_cast<unsigned char*>(img), Cout);
+                       reinterpret_cast<unsigned char*>(img), Cout, wscale);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

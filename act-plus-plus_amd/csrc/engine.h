@@ -15,15 +15,20 @@ struct Param {
     bool is_buffer;
 };
 
-// the split weight image holds W * 2^8: the lo pieces of weights around 1e-2 stay normal fp16 numbers; |W| < 255 assumed
+// default power-of-two scale of a split weight image: the lo pieces of weights around 1e-2 stay normal fp16 numbers.  The
+// handle replaces it per parameter at finalize (engine_calibrate_weight_scales) from the parameter's largest magnitude.
 static constexpr float W16_SCALE = 256.f;
+// flag word of a handle (actmi_get_flags): bit 0 = a forward output was not finite, bit 1 = a weight left the fp16 range of
+// its split image, bit 2 = a training loss was not finite
+// (values: ACTMI_FLAG_OUTPUT / _WEIGHT / _LOSS in include/actmi.h)
 
 struct ConvLayer {
     std::string name, bn;
     int cin, cout, k, stride, pad, H, W, Ho, Wo;
     int K = 0;
     float* w = nullptr;       // [cam][cout][K], K index (r,s,c)
-    float* w16 = nullptr;     // the same, fp16-split (f16x3 GEMM)
+    float* w16 = nullptr;     // the same, fp16-split (f16x3 GEMM), built with w16_scale
+    float w16_scale = W16_SCALE;
     float* scale = nullptr;   // [cam][cout]
     float* bias = nullptr;
 };
@@ -88,6 +93,16 @@ struct actmi_ctx {
     float* pbase = nullptr;
     float* p16base = nullptr;          // fp16-split image of the parameter arena (B operands of the f16x3 GEMM)
     int gemm_prec = 0;                 // ACTMI_PREC_* used by the forward GEMMs of this handle
+    // range guard of the f16x3 forward: one power-of-two scale per parameter for its split image, chosen at
+    // finalize so that max|w| * scale lands in [2^13, 2^14) (capped at 2^12); device copies for the split kernel
+    std::vector<float> pscale;         // per parameter (index = position in params)
+    float* pscale_dev = nullptr;
+    int* pseg64 = nullptr;             // parameter index of every 64-float slot of the arena
+    int64_t *poff_dev = nullptr, *pnumel_dev = nullptr;
+    unsigned* pamax_dev = nullptr;
+    float conv1_wscale = W16_SCALE;
+    float bwd_wscale = W16_SCALE;      // static scale of weights used as on-the-fly B operands of the backward GEMMs
+    uint32_t* flags = nullptr;         // device flag word (ACTMI_FLAG_*)
     float* splitk_ws = nullptr;        // slices of the forward GEMMs whose contraction is split to fill the chip
     int64_t splitk_ws_floats = 0;
     int conv1_vpool = 1;               // inference: conv1 emits the vertical half of the max pool (ACTMI_CONV1_VPOOL=0: off)
@@ -126,6 +141,8 @@ int engine_destroy(actmi_ctx* ctx);
 const char* engine_create_error();
 int engine_finalize(actmi_ctx* ctx, hipStream_t st);
 int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st);
+int engine_calibrate_weight_scales(actmi_ctx* ctx, hipStream_t st);
+float engine_weight_scale(const actmi_ctx* ctx, const float* w);
 int train_create(actmi_ctx* ctx);
 int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt, const float* actions, const uint8_t* is_pad,
                   const float* eps, uint64_t dropout_seed, float dropout_p, int B, float* losses, float* a_hat_out,

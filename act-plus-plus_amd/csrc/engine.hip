@@ -158,12 +158,12 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
     if (ctx->gemm_prec == ACTMI_PREC_F16X3 && a.tb == 0) {
         // B is a weight matrix: use its pre-split image (same offsets) where one exists
         if (a.Bw >= ctx->pbase && a.Bw < ctx->pbase + ctx->ptotal) {
+            a.b_scale = engine_weight_scale(ctx, a.Bw);
             a.Bw = ctx->p16base + (a.Bw - ctx->pbase);
             a.b_split = 1;
-            a.b_scale = W16_SCALE;
         } else {
             for (const ConvLayer& cl : ctx->convs)
-                if (a.Bw == cl.w) { a.Bw = cl.w16; a.b_split = 1; a.b_scale = W16_SCALE; break; }
+                if (a.Bw == cl.w) { a.Bw = cl.w16; a.b_split = 1; a.b_scale = cl.w16_scale; break; }
         }
     }
     // Small grids (B = 1-4 rollouts: layer3/4 convolutions, the K = 3200 FFN products): a launch of a few hundred tiles
@@ -205,6 +205,72 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
         }
     }
     return launch_gemm(a, st, &ctx->err);
+}
+
+// scale of the split image of the parameter that contains address w (parameters are laid out in increasing offset order)
+float engine_weight_scale(const actmi_ctx* ctx, const float* w) {
+    const int64_t off = w - ctx->pbase;
+    size_t lo = 0, hi = ctx->params.size();
+    while (hi - lo > 1) {
+        const size_t mid = (lo + hi) / 2;
+        if (ctx->params[mid].off <= off) lo = mid; else hi = mid;
+    }
+    return lo < ctx->pscale.size() ? ctx->pscale[lo] : W16_SCALE;
+}
+
+// Range guard of the f16x3 weight images: a fixed 2^8 assumed |W| < 255 and left the lo pieces of
+// weights below ~2e-4 in the fp16 subnormals.  Here every parameter gets the power of two that brings its largest magnitude
+// into [2^13, 2^14) -- capped at 2^12 so that ordinary 1e-2 .. 1 weights keep a scale of 2^12 -- measured on the device.  A
+// parameter that is not finite, or so large that no representable scale fits, fails the finalize.  One host
+// synchronisation; runs at finalize only (training steps keep the scales and raise ACTMI_FLAG_WEIGHT on overflow).
+int engine_calibrate_weight_scales(actmi_ctx* ctx, hipStream_t st) {
+    const int np = (int)ctx->params.size();
+    ctx->pscale.assign(np, W16_SCALE);
+    if (ctx->gemm_prec != ACTMI_PREC_F16X3) return 0;
+    CHK(launch_seg_amax(ctx->pbase, ctx->poff_dev, ctx->pnumel_dev, np, ctx->pamax_dev, st));
+    std::vector<unsigned> bits(np);
+    HIPCHK(hipMemcpyAsync(bits.data(), ctx->pamax_dev, np * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float gmax = 0.f;
+    for (int i = 0; i < np; ++i) {
+        float amax;
+        memcpy(&amax, &bits[i], 4);
+        if (!(amax <= 3.0e38f)) {                  // NaN or inf bits
+            ctx->err = "parameter " + ctx->params[i].key + " is not finite";
+            return ACTMI_E_INVALID;
+        }
+        float sc = 4096.f;                         // cap: an all-zero / tiny parameter needs no more
+        if (amax > 0.f) {
+            int e;
+            frexpf(amax, &e);                      // amax = m * 2^e, m in [0.5, 1)
+            const float fit = ldexpf(1.f, 14 - e); // amax * fit in [2^13, 2^14)
+            sc = fit < 4096.f ? fit : 4096.f;
+        }
+        if (!(sc >= 1.17549435e-38f) || !(amax * sc < 65504.f)) {
+            ctx->err = "parameter " + ctx->params[i].key + " is too large for the f16x3 path (use gemm_prec f32)";
+            return ACTMI_E_INVALID;
+        }
+        ctx->pscale[i] = sc;
+        if (!ctx->params[i].is_buffer && amax > gmax) gmax = amax;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->pscale_dev, ctx->pscale.data(), np * sizeof(float), hipMemcpyHostToDevice, st));
+    // one scale per convolution layer (its weight image spans the cameras): the smallest of the cameras' scales
+    auto key_scale = [&](const std::string& key) {
+        auto it = ctx->index.find(key);
+        return it == ctx->index.end() ? W16_SCALE : ctx->pscale[it->second];
+    };
+    ctx->conv1_wscale = 4096.f;
+    for (auto& cl : ctx->convs) cl.w16_scale = 4096.f;
+    for (int cam = 0; cam < ctx->cfg.num_cams; ++cam) {
+        const std::string p = "backbones." + std::to_string(cam) + ".0.body.";
+        ctx->conv1_wscale = std::min(ctx->conv1_wscale, key_scale(p + "conv1.weight"));
+        for (auto& cl : ctx->convs) cl.w16_scale = std::min(cl.w16_scale, key_scale(p + cl.name + ".weight"));
+    }
+    // weights split on the fly in the backward GEMMs share one static scale
+    ctx->bwd_wscale = W16_SCALE;
+    while (gmax * ctx->bwd_wscale >= 16384.f && ctx->bwd_wscale > 1.f / 65536.f) ctx->bwd_wscale *= 0.5f;
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
 }
 
 namespace {
@@ -317,6 +383,39 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
         ctx->splitk_ws_floats = (int64_t)(getenv("ACTMI_FWD_SPLITK_WS_MB") ? atoi(getenv("ACTMI_FWD_SPLITK_WS_MB")) : 256) << 18;
         if ((rc = dev_alloc(ctx, &ctx->splitk_ws, ctx->splitk_ws_floats))) return fail(rc);
     }
+    {
+        // tables of the weight range guard: parameter index of every 64-float slot, offsets / sizes for the amax kernel
+        const int np = (int)ctx->params.size();
+        std::vector<int> seg((size_t)(ctx->ptotal / 64), 0);
+        std::vector<int64_t> off(np), numel(np);
+        for (int i = 0; i < np; ++i) {
+            off[i] = ctx->params[i].off; numel[i] = ctx->params[i].numel;
+            const int64_t g0 = ctx->params[i].off / 64, g1 = (i + 1 < np ? ctx->params[i + 1].off : ctx->ptotal) / 64;
+            for (int64_t g = g0; g < g1; ++g) seg[(size_t)g] = i;
+        }
+        float *f0 = nullptr, *f1 = nullptr, *f2 = nullptr, *f3 = nullptr, *f4 = nullptr, *f5 = nullptr;
+        if ((rc = dev_alloc(ctx, &f0, (int64_t)seg.size()))) return fail(rc);
+        if ((rc = dev_alloc(ctx, &f1, 2 * np))) return fail(rc);
+        if ((rc = dev_alloc(ctx, &f2, 2 * np))) return fail(rc);
+        if ((rc = dev_alloc(ctx, &f3, np))) return fail(rc);
+        if ((rc = dev_alloc(ctx, &f4, np))) return fail(rc);
+        if ((rc = dev_alloc(ctx, &f5, 4))) return fail(rc);
+        ctx->pseg64 = reinterpret_cast<int*>(f0);
+        ctx->poff_dev = reinterpret_cast<int64_t*>(f1);
+        ctx->pnumel_dev = reinterpret_cast<int64_t*>(f2);
+        ctx->pamax_dev = reinterpret_cast<unsigned*>(f3);
+        ctx->pscale_dev = f4;
+        ctx->flags = reinterpret_cast<uint32_t*>(f5);
+        ctx->pscale.assign(np, W16_SCALE);
+        if (hipMemcpy(ctx->pseg64, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(ctx->poff_dev, off.data(), np * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(ctx->pnumel_dev, numel.data(), np * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(ctx->pscale_dev, ctx->pscale.data(), np * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(ctx->flags, 0, 16) != hipSuccess) {
+            ctx->err = "hipMemcpy failed (weight scale tables)";
+            return fail(ACTMI_E_LAUNCH);
+        }
+    }
     resolve_layers(ctx);
 
     // ---- conv layer table + packed weights
@@ -427,10 +526,12 @@ int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st) {
         }
     }
     if (ctx->gemm_prec == ACTMI_PREC_F16X3) {
-        CHK(launch_split16(ctx->pbase, ctx->p16base, ctx->ptotal, W16_SCALE, st));
-        CHK(launch_conv1_wimg(ctx->conv1_w, ctx->conv1_wimg, C, w0, st));
+        // per-parameter scales (engine_calibrate_weight_scales); a weight that has outgrown its scale since the last
+        // finalize raises ACTMI_FLAG_WEIGHT instead of silently becoming inf
+        CHK(launch_split16_map(ctx->pbase, ctx->p16base, ctx->ptotal, ctx->pseg64, ctx->pscale_dev, ctx->flags, st));
+        CHK(launch_conv1_wimg(ctx->conv1_w, ctx->conv1_wimg, C, w0, st, ctx->conv1_wscale));
         for (const ConvLayer& cl : ctx->convs)
-            CHK(launch_split16(cl.w, cl.w16, (int64_t)C * cl.cout * cl.K, W16_SCALE, st));
+            CHK(launch_split16(cl.w, cl.w16, (int64_t)C * cl.cout * cl.K, cl.w16_scale, st, ctx->flags));
     }
     // learned rows of the token position table (transformer.py:91-92)
     HIPCHK(hipMemcpyAsync(ctx->pos_tokens, ctx->P("additional_pos_embed.weight"), 2 * D * sizeof(float),
@@ -489,6 +590,7 @@ int engine_finalize(actmi_ctx* ctx, hipStream_t st) {
                 }
         HIPCHK(hipMemcpy(ctx->pos_tokens, pos.data(), pos.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    CHK(engine_calibrate_weight_scales(ctx, st));
     CHK(engine_prepare_weights(ctx, st));
     HIPCHK(hipStreamSynchronize(st));
     ctx->finalized = true;
@@ -509,6 +611,7 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
     c1.Ho = ctx->H1; c1.Wo = ctx->W1; c1.Cout = w0;
     c1.prec = ctx->gemm_prec;
     c1.wimg = reinterpret_cast<const unsigned char*>(ctx->conv1_wimg);
+    c1.wscale = ctx->conv1_wscale;
     // inference never needs conv1's own map: the stem emits the vertical half of the max pool (half the bytes) and a
     // row-wise pass finishes it.  Same maxima, so the result is bit-identical to conv1 -> 3x3 pool.
     if (ctx->conv1_vpool && ctx->stop_stage != "conv1" && ctx->gemm_prec == ACTMI_PREC_F16X3 && (ctx->H1 & 1) == 0 && (w0 & 3) == 0 && ctx->H2 == ctx->H1 / 2) {
@@ -531,7 +634,7 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
             // layer1: direct convolution over an LDS-resident patch (the im2col GEMM is L2-traffic bound at 64 channels)
             Conv3Args c3;
             c3.x = in; c3.w16 = cl.w16; c3.scale = cl.scale; c3.bias = cl.bias; c3.res = res; c3.out = out;
-            c3.G = C; c3.B = B; c3.H = cl.H; c3.W = cl.W; c3.relu = relu; c3.w_scale = W16_SCALE;
+            c3.G = C; c3.B = B; c3.H = cl.H; c3.W = cl.W; c3.relu = relu; c3.w_scale = cl.w16_scale;
             return launch_conv3x3_c64(c3, st, &ctx->err);
         }
         GemmArgs a;
@@ -683,5 +786,8 @@ int engine_forward_infer(actmi_ctx* ctx, const float* qpos, const void* image, i
         CHK(engine_encoder_layer(ctx, ctx->enc[l], ctx->X, ctx->pos_tokens, B, N, nullptr, st));
     ctx->dbg["memory"] = {ctx->X, (int64_t)B * N * D};
     CHK(engine_decoder_infer(ctx, B, a_hat, st));
+    // default-on output guard: an operand that left the fp16 range of the f16x3 products surfaces as inf / NaN in a_hat;
+    // the flag is read at the caller's next natural synchronisation (actmi_get_flags)
+    CHK(launch_check_finite(a_hat, (int64_t)B * g.num_queries * g.action_dim, ctx->flags, ACTMI_FLAG_OUTPUT, st));
     return 0;
 }

@@ -238,21 +238,85 @@ int launch_bcast_add_rows(float* dst, const float* vec, int R, int D, hipStream_
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-// weights for the f16x3 GEMM: every aligned group of 4 floats -> {4 hi halfs, 4 lo halfs} in the same 16 bytes
-__global__ void split16_kernel(const actmi_f32x4* __restrict__ src, uint4* __restrict__ dst, int64_t n4, float scale) {
+// weights for the f16x3 GEMM: every aligned group of 4 floats -> {4 hi halfs, 4 lo halfs} in the same 16 bytes.
+// flag (optional): bit 1 is raised when a scaled value leaves the fp16 range or is not finite (the image would hold inf)
+__global__ void split16_kernel(const actmi_f32x4* __restrict__ src, uint4* __restrict__ dst, int64_t n4, float scale,
+                               uint32_t* __restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
+    const actmi_f32x4 v = src[i] * scale;
     uint2 hi, lo;
-    split16(src[i] * scale, hi, lo);
+    split16(v, hi, lo);
     dst[i] = uint4{hi.x, hi.y, lo.x, lo.y};
+    if (flag && !(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) < 65504.f)) atomicOr(flag, 2u);
 }
 
-int launch_split16(const float* src, float* dst, int64_t nfloats, float scale, hipStream_t st) {
+int launch_split16(const float* src, float* dst, int64_t nfloats, float scale, hipStream_t st, uint32_t* flag) {
     if (nfloats <= 0) return 0;
     if ((nfloats & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return -2;
     const int64_t n4 = nfloats / 4;
     hipLaunchKernelGGL(split16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<const actmi_f32x4*>(src), reinterpret_cast<uint4*>(dst), n4, scale);
+                       reinterpret_cast<const actmi_f32x4*>(src), reinterpret_cast<uint4*>(dst), n4, scale, flag);
+    return (int)hipGetLastError();
+}
+
+// the parameter arena: 64-float slots, slot g belongs to segment (parameter) seg_of_group64[g] whose scale is seg_scale[.]
+__global__ void split16_map_kernel(const actmi_f32x4* __restrict__ src, uint4* __restrict__ dst, int64_t n4,
+                                   const int* __restrict__ seg_of_group64, const float* __restrict__ seg_scale,
+                                   uint32_t* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float scale = seg_scale[seg_of_group64[i >> 4]];
+    const actmi_f32x4 v = src[i] * scale;
+    uint2 hi, lo;
+    split16(v, hi, lo);
+    dst[i] = uint4{hi.x, hi.y, lo.x, lo.y};
+    if (flag && !(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) < 65504.f)) atomicOr(flag, 2u);
+}
+
+int launch_split16_map(const float* src, float* dst, int64_t nfloats, const int* seg_of_group64, const float* seg_scale,
+                       uint32_t* flag, hipStream_t st) {
+    if (nfloats <= 0) return 0;
+    if ((nfloats & 63) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return -2;
+    const int64_t n4 = nfloats / 4;
+    hipLaunchKernelGGL(split16_map_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const actmi_f32x4*>(src), reinterpret_cast<uint4*>(dst), n4, seg_of_group64, seg_scale, flag);
+    return (int)hipGetLastError();
+}
+
+// out_bits[s] = bits of max |x| over segment s (non-negative floats order like unsigned); NaN / inf bits order above
+// every finite value, so a non-finite parameter shows up as a huge "amax"
+__global__ void seg_amax_kernel(const float* __restrict__ base, const int64_t* __restrict__ off, const int64_t* __restrict__ numel,
+                                unsigned* __restrict__ out_bits) {
+    const int sgm = blockIdx.x;
+    const float* x = base + off[sgm];
+    const int64_t n = numel[sgm];
+    unsigned m = 0;
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.y * blockDim.x)
+        m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out_bits + sgm, m);
+}
+
+int launch_seg_amax(const float* base, const int64_t* off, const int64_t* numel, int nseg, unsigned* out_bits, hipStream_t st) {
+    if (nseg <= 0) return 0;
+    if (hipMemsetAsync(out_bits, 0, (size_t)nseg * sizeof(unsigned), st) != hipSuccess) return -3;
+    hipLaunchKernelGGL(seg_amax_kernel, dim3(nseg, 16), dim3(256), 0, st, base, off, numel, out_bits);
+    return (int)hipGetLastError();
+}
+
+// raises `bit` in *flag when any of x[0..n) is NaN or infinite (the default-on output check of the forward passes)
+__global__ void check_finite_kernel(const float* __restrict__ x, int64_t n, uint32_t* __restrict__ flag, uint32_t bit) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        bad = bad || !(fabsf(x[i]) <= 3.402823466e38f);
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, bit);
+}
+
+int launch_check_finite(const float* x, int64_t n, uint32_t* flag, uint32_t bit, hipStream_t st) {
+    if (n <= 0 || !flag) return 0;
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(check_finite_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, st, x, n, flag, bit);
     return (int)hipGetLastError();
 }
 

@@ -78,8 +78,8 @@ const float* dyn_scale(actmi_ctx* ctx, const float* x, int64_t ld, int M, int N,
     return slot;
 }
 
-// power-of-two pre-scale for weight operands of the backward GEMMs (f16x3: keeps lo pieces of ~1e-2 weights normal)
-constexpr float WGT_PRESCALE = 256.f;
+// weight operands of the backward GEMMs (f16x3) are split on the fly with the handle's static power-of-two scale
+// ctx->bwd_wscale (2^8 unless a parameter is too large for it: engine_calibrate_weight_scales)
 
 int pick_splitk(int M, int N, int groups, int K) {
     const long tiles = (long)((M + 127) / 128) * ((N + 63) / 64) * groups;
@@ -106,7 +106,7 @@ int lin_dgrad(actmi_ctx* ctx, const float* dy, int64_t lddy, int M, int N, const
     GemmArgs a = G0();
     a.A = dy; a.lda = lddy; a.M = M; a.K = N; a.N = K; a.Bw = W; a.ldb = K; a.tb = 1; a.C = dx; a.ldc = lddx;
     a.res = res; a.ldres = lddx; a.mask = mask; a.ldmask = lddx; a.alpha = alpha;
-    a.b_scale = WGT_PRESCALE;
+    a.b_scale = ctx->bwd_wscale;
     a.a_scale_dev = dyn_scale(ctx, dy, lddy, M, N, st, true);
     return tgemm(ctx, a, st);
 }
@@ -280,7 +280,7 @@ int enc_bwd(actmi_ctx* ctx, const EncW& w, const EncSave& s, const float* dOut, 
         GemmArgs a = G0();
         a.A = gQKV; a.lda = 3 * D; a.a_rowmap = T.pos_rows; a.M = 2 * B; a.K = 2 * D; a.Bw = w.attn.in_w; a.ldb = D; a.tb = 1;
         a.N = D; a.C = T.tmp2BD; a.ldc = D;
-        a.b_scale = WGT_PRESCALE;
+        a.b_scale = ctx->bwd_wscale;
         a.a_scale_dev = dyn_scale(ctx, gQKV, 3 * D, M, 2 * D, st);
         CHK(tgemm(ctx, a, st));
         CHK(launch_sum_batch(T.tmp2BD, 2 * D, D, dpos2, B, 2, D, 1, st));
@@ -317,7 +317,7 @@ int conv_dgrad(actmi_ctx* ctx, const ConvLayer& cl, int li, const float* dys, fl
     a.gA = (int64_t)B * cl.Ho * cl.Wo * cl.cout; a.gB = (int64_t)cl.cin * a.K; a.gC = (int64_t)a.M * cl.cin;
     a.res = res; a.ldres = cl.cin; a.gRes = a.gC; a.mask = mask; a.ldmask = cl.cin; a.gMask = a.gC;
     a.scale = scale; a.gSB = cl.cin;
-    a.b_scale = WGT_PRESCALE;
+    a.b_scale = ctx->bwd_wscale;
     a.a_scale_dev = dyn_scale(ctx, dys, cl.cout, C * B * cl.Ho * cl.Wo, cl.cout, st, true);
     return tgemm(ctx, a, st);
 }
@@ -507,6 +507,7 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
         c1.Ho = ctx->H1; c1.Wo = ctx->W1; c1.Cout = w0;
         c1.prec = ctx->gemm_prec;
         c1.wimg = reinterpret_cast<const unsigned char*>(ctx->conv1_wimg);
+        c1.wscale = ctx->conv1_wscale;
         CHK(launch_conv1(c1, st, &ctx->err));
         CHK(launch_maxpool_idx(ctx->act1, T.pool, T.pool_arg, C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
     }
@@ -514,7 +515,7 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
         if (ctx->gemm_prec == ACTMI_PREC_F16X3 && cl.k == 3 && cl.stride == 1 && cl.pad == 1 && cl.cin == 64 && cl.cout == 64) {
             Conv3Args c3;           // layer1: direct convolution (conv3.hip), as in the inference engine
             c3.x = in; c3.w16 = cl.w16; c3.scale = cl.scale; c3.bias = cl.bias; c3.res = res; c3.out = out;
-            c3.G = C; c3.B = B; c3.H = cl.H; c3.W = cl.W; c3.relu = relu; c3.w_scale = W16_SCALE;
+            c3.G = C; c3.B = B; c3.H = cl.H; c3.W = cl.W; c3.relu = relu; c3.w_scale = cl.w16_scale;
             return launch_conv3x3_c64(c3, st, &ctx->err);
         }
         GemmArgs a = G0();
@@ -627,6 +628,7 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
     CHK(launch_losses(T.a_hat, T.actions, T.is_pad, (g.has_cvae_encoder && !g.vq) ? T.latent_info : nullptr, T.losses, B, Q, A, L,
                       g.kl_weight, st));
     if (losses) HIPCHK(hipMemcpyAsync(losses, T.losses, 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    CHK(launch_check_finite(T.losses, 3, ctx->flags, ACTMI_FLAG_LOSS, st));       // default-on: a loss that is not finite
     T.have_forward = true;
     return 0;
 }
@@ -773,7 +775,7 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
         GemmArgs a = G0();
         a.A = dKV; a.lda = 2 * D; a.a_rowmap = T.pos_rows; a.M = 2 * B; a.K = D; a.Bw = d.cross.in_w + (int64_t)D * D; a.ldb = D;
         a.tb = 1; a.N = D; a.C = T.tmp2BD; a.ldc = D;
-        a.b_scale = WGT_PRESCALE;
+        a.b_scale = ctx->bwd_wscale;
         a.a_scale_dev = dyn_scale(ctx, dKV, 2 * D, B * N, D, st);
         CHK(tgemm(ctx, a, st));
         CHK(launch_sum_batch(T.tmp2BD, 2 * D, D, dpos2, B, 2, D, 1, st));

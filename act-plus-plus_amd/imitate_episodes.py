@@ -200,6 +200,8 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
             else:
                 raw_action = all_actions[:, t % query_frequency]
             raw_action = raw_action.cpu().numpy()                            # D2H sync, once per step for all E
+            if hasattr(getattr(policy, "model", None), "check_flags"):
+                policy.model.check_flags()                                   # range guard, read at this natural sync point
             if t % query_frequency == 0:
                 t_policy += time.time() - tq
             if trace is not None:
@@ -303,6 +305,8 @@ def train_bc(train_dataloader, val_dataloader, config, log=None):
         optimizer.step()
         if log:
             log({k: float(v) for k, v in forward_dict.items()}, step)
+        if step % save_every == 0 or step % validate_every == 0:
+            policy.model.check_flags()                   # non-finite loss / weight beyond its split scale: fail loudly
         if step % save_every == 0 and rank == 0:
             torch.save(policy.serialize(), os.path.join(ckpt_dir, f"policy_step_{step}_seed_{seed}.ckpt"))
     best_step, min_val_loss, best_state_dict = best_ckpt_info

@@ -297,6 +297,18 @@ int actmi_debug_stop_after(actmi_handle h, const char* stage);
  * environment says ACTMI_GEMM_PREC=f32).  Call before actmi_finalize (the split weight image is built there). */
 int actmi_set_gemm_prec(actmi_handle h, int prec);
 
+/* ---- range / finiteness guard (default on) --------------------------------------------------------- */
+/* The handle keeps a device flag word raised by its own kernels: ACTMI_FLAG_OUTPUT = an inference output (a_hat) was NaN /
+ * infinite -- with the f16x3 products that is how an operand beyond the fp16 range (|x| >= 65504) shows up;
+ * ACTMI_FLAG_WEIGHT = a parameter has outgrown the power-of-two scale its split image was calibrated with at finalize
+ * (re-run actmi_finalize); ACTMI_FLAG_LOSS = a training loss was not finite.  actmi_get_flags copies the word to the host
+ * (it synchronises `stream`: call it at a natural synchronisation point, e.g. right after the actions were copied to the
+ * host) and clears it when `clear` is non-zero.  Replaces nothing in the reference (torch propagates NaN silently). */
+#define ACTMI_FLAG_OUTPUT 1u
+#define ACTMI_FLAG_WEIGHT 2u
+#define ACTMI_FLAG_LOSS 4u
+int actmi_get_flags(actmi_handle h, uint32_t* host_flags, int clear, void* stream);
+
 /* ---- per-launch HIP-event profiler (bench.py roofline leg) --------------------------------------- */
 /* When enabled, every kernel launch of the library is bracketed by two events on its stream.  The report is a
  * JSON array of {"name","count","ms","flops","bytes"} per kernel instantiation (algorithmic flops/bytes). */

@@ -1,0 +1,149 @@
+"""Range guard of the f16x3 arithmetic (VERDICT r01 weak #1 / ADVICE low): split weight images carry one power-of-two scale
+per parameter measured at finalize (not a fixed 2^8 that assumed |W| < 255), and a device flag -- default on, read at the
+caller's synchronisation points -- reports non-finite outputs / losses and weights that outgrew their scale.
+Whole-model runs with rescaled layer groups and extreme images, f16x3 against the CPU oracle at the 1e-4 bar."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import torch_sd  # noqa: E402
+from actmi import weights as W  # noqa: E402
+from actmi.config import tiny_config  # noqa: E402
+from actmi.engine import ACTEngine  # noqa: E402
+
+ATOL = 1e-4
+
+
+def _oracle(cfg, sd_np, inp):
+    from oracle import act_ref as R
+    with torch.no_grad():
+        return R.policy_call(torch_sd(sd_np), cfg, torch.from_numpy(inp["qpos"]),
+                             torch.from_numpy(W.u8_nhwc_to_f32_nchw(inp["image_u8"]))).numpy()
+
+
+def _hip(cfg, sd_np, inp, prec="f16x3"):
+    eng = ACTEngine(cfg, max_batch=inp["qpos"].shape[0], gemm_prec=prec)
+    eng.load_state_dict(sd_np)
+    eng.finalize()
+    a = eng.forward_infer(torch.from_numpy(inp["qpos"]).cuda(), torch.from_numpy(inp["image_u8"]).cuda()).cpu().numpy()
+    eng.check_flags()
+    return a
+
+
+def _scale_group(sd, pred, factor):
+    out = dict(sd)
+    n = 0
+    for k, v in sd.items():
+        if pred(k):
+            out[k] = (v * np.float32(factor)).astype(np.float32)
+            n += 1
+    assert n > 0
+    return out
+
+
+CASES = {
+    # every Linear / attention weight matrix of the main encoder 1000x smaller (LayerNorm renormalises the stream)
+    "encoder_weights_x1e-3": lambda sd: _scale_group(sd, lambda k: k.startswith("transformer.encoder.") and k.endswith("weight")
+                                                     and "norm" not in k, 1e-3),
+    # backbone convolution weights 1000x smaller, FrozenBN gain 1000x larger: same function, tiny conv operands
+    "backbone_convs_x1e-3_bn_x1e3": lambda sd: _scale_group(
+        _scale_group(sd, lambda k: "backbones" in k and "conv" in k and k.endswith("weight"), 1e-3),
+        lambda k: "backbones" in k and ("bn1.weight" in k or "bn2.weight" in k) and "layer" in k, 1e3),
+    # an output layer with weights far beyond the |W| < 255 assumption of the old fixed 2^8 scale (|W| up to ~1e3), and a
+    # projection 30x larger than usual (its tokens reach ~1e3: still inside the activation range)
+    "action_head_x10000_input_proj_x30": lambda sd: _scale_group(
+        _scale_group(sd, lambda k: k == "input_proj.weight", 30.0), lambda k: k.startswith("action_head."), 10000.0),
+    "decoder_weights_x1e2": lambda sd: _scale_group(sd, lambda k: k.startswith("transformer.decoder.layers.0.") and k.endswith("weight")
+                                                    and "norm" not in k, 1e2),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_rescaled_layer_groups_match_the_oracle(case):
+    cfg = tiny_config(camera_names=["a", "b", "c"], image_h=96, image_w=128)
+    sd_np = CASES[case](W.generate_state_dict(cfg, seed=17))
+    inp = W.generate_inputs(cfg, 2, seed=5)
+    exp = _oracle(cfg, sd_np, inp)
+    got = _hip(cfg, sd_np, inp)
+    err = float(np.abs(got - exp).max())
+    scale = max(1.0, float(np.abs(exp).max()))
+    print(f"{case}: max|a_hat - oracle| = {err:.3e} (|a_hat| max {np.abs(exp).max():.3e})")
+    assert np.isfinite(got).all() and err <= ATOL * scale
+
+
+@pytest.mark.parametrize("value", [0, 255])
+def test_constant_images(value):
+    cfg = tiny_config()
+    sd_np = W.generate_state_dict(cfg, seed=3)
+    inp = W.generate_inputs(cfg, 2, seed=5)
+    inp["image_u8"][:] = value
+    exp = _oracle(cfg, sd_np, inp)
+    got = _hip(cfg, sd_np, inp)
+    assert float(np.abs(got - exp).max()) <= ATOL
+
+
+def test_weight_scales_are_per_parameter():
+    """a parameter of magnitude 1e-4 and one of magnitude 1e3 in the same model both keep ~22 bits in their split images"""
+    from actmi import ops
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(300, 256, generator=g)
+    for mag in (1e-4, 1e3):
+        Wt = torch.randn(128, 256, generator=g) * mag
+        amax = float(Wt.abs().max())
+        sc = min(4096.0, 2.0 ** (14 - np.frexp(amax)[1]))
+        assert 8192.0 <= amax * sc < 16384.0 or sc == 4096.0
+        got = ops.gemm(A.cuda(), ops.split16(Wt.cuda(), sc), prec="f16x3", w_split=sc)
+        exp = A.double() @ Wt.double().t()
+        assert float((got.cpu().double() - exp).abs().max() / exp.abs().max()) < 2e-6
+
+
+def test_non_finite_parameter_fails_finalize():
+    cfg = tiny_config()
+    sd_np = W.generate_state_dict(cfg, seed=3)
+    sd_np = dict(sd_np)
+    bad = sd_np["input_proj.weight"].copy()
+    bad[0, 0] = np.inf
+    sd_np["input_proj.weight"] = bad
+    eng = ACTEngine(cfg, max_batch=1, gemm_prec="f16x3")
+    eng.load_state_dict(sd_np)
+    with pytest.raises(RuntimeError, match="not finite"):
+        eng.finalize()
+
+
+def test_output_flag_is_raised_and_cleared():
+    """an activation beyond the fp16 range of the split products becomes inf / NaN in a_hat: the default-on flag reports it
+    at the next check, and a clean step afterwards passes"""
+    cfg = tiny_config()
+    sd_np = W.generate_state_dict(cfg, seed=3)
+    inp = W.generate_inputs(cfg, 2, seed=5)
+    eng = ACTEngine(cfg, max_batch=2, gemm_prec="f16x3")
+    eng.load_state_dict(sd_np)
+    eng.finalize()
+    q, im = torch.from_numpy(inp["qpos"]).cuda(), torch.from_numpy(inp["image_u8"]).cuda()
+    eng.forward_infer(q, im)
+    assert eng.read_flags() == 0
+    eng.forward_infer(q * 1e30, im)                        # proprio token ~1e29: far outside |x| < 65504
+    with pytest.raises(FloatingPointError, match="not finite"):
+        eng.check_flags()
+    eng.forward_infer(q, im)
+    eng.check_flags()                                      # cleared by the failed check, clean again
+    # the native fp32 path takes the same input without complaint only while fp32 itself holds; 1e4 is fine for both
+    eng.forward_infer(q * 1e3, im)
+    eng.check_flags()
+
+
+def test_weight_that_outgrows_its_scale_raises_the_weight_flag():
+    cfg = tiny_config()
+    eng = ACTEngine(cfg, max_batch=2, training=True, gemm_prec="f16x3")
+    eng.load_state_dict(W.generate_state_dict(cfg, seed=3))
+    eng.finalize()
+    inp = W.generate_inputs(cfg, 2, seed=5, with_actions=True)
+    t = {k: torch.from_numpy(v).cuda() for k, v in inp.items()}
+    eng.zero_grad()
+    eng.forward_train(t["qpos"], t["image_u8"], t["actions"], t["is_pad"], eps=t["eps"])
+    eng.backward(1.0)
+    eng.adamw_step(1e3, 1e3, 0.0, step=1)                  # absurd learning rate: |w| jumps by ~1e3 per element
+    f = eng.read_flags()
+    assert f & ACTEngine.FLAG_WEIGHT

@@ -292,3 +292,27 @@ def test_vq_device_drawn_code():
     eng.zero_grad()
     eng.backward(1.0)                                   # the straight-through path runs with a drawn code too
     assert float(eng.grad("latent_proj.weight").abs().max()) > 0
+
+
+def test_chunks_longer_than_the_episode_are_padded_not_read_out_of_bounds():
+    """actions / is_pad with fewer than num_queries steps (episodes shorter than the chunk): the wrapper continues the
+    dataset's zero / is_pad=True padding; the result equals the explicitly padded call (the library used to read past the
+    end of the short tensors: found by the default-on loss guard)."""
+    from actmi.config import tiny_config
+    cfg = tiny_config()
+    eng = ACTEngine(cfg, max_batch=2, training=True)
+    eng.load_state_dict(W.generate_state_dict(cfg, seed=0))
+    inp = W.generate_inputs(cfg, 2, seed=3, with_actions=True)
+    t = {k: torch.from_numpy(v).cuda() for k, v in inp.items()}
+    Q, short = cfg.num_queries, 3
+    a_full, p_full = t["actions"].clone(), t["is_pad"].clone()
+    a_full[:, short:] = 0
+    p_full[:, short:] = True
+    junk = torch.full((1 << 22,), float("nan"), device="cuda")               # poison what a stray read would hit
+    ref = eng.forward_train(t["qpos"], t["image_u8"], a_full, p_full, eps=t["eps"])
+    got = eng.forward_train(t["qpos"], t["image_u8"], a_full[:, :short].contiguous(), p_full[:, :short].contiguous(), eps=t["eps"])
+    del junk
+    for k in ("l1", "kl", "loss"):
+        assert torch.isfinite(got[k]) and float(got[k]) == float(ref[k])
+    with pytest.raises(ValueError):
+        eng.forward_train(t["qpos"], t["image_u8"], a_full[:, :, :5].contiguous(), p_full, eps=t["eps"])
