@@ -22,7 +22,8 @@ template <int NV>     // float4 per lane actually needed (ceil(D/256)): no dead 
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ dy, const float* __restrict__ dx_add,
                                                      float* __restrict__ dx, float* __restrict__ dw,
-                                                     float* __restrict__ db, int M, int D, float eps) {
+                                                     float* __restrict__ db, int M, int D, float eps,
+                                                     float* __restrict__ part) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nw = gridDim.x * 4;
@@ -98,12 +99,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int k = c * 4 + e;
-                    atomicAdd(&dw[k], aw[i][e] + s_part[0][0][k] + s_part[0][1][k] + s_part[0][2][k]);
-                    atomicAdd(&db[k], ab[i][e] + s_part[1][0][k] + s_part[1][1][k] + s_part[1][2][k]);
+                    const float sw = aw[i][e] + s_part[0][0][k] + s_part[0][1][k] + s_part[0][2][k];
+                    const float sb = ab[i][e] + s_part[1][0][k] + s_part[1][1][k] + s_part[1][2][k];
+                    if (part) {          // deterministic form: one row of partials per block, summed in block order afterwards
+                        part[((int64_t)blockIdx.x * 2 + 0) * D + k] = sw;
+                        part[((int64_t)blockIdx.x * 2 + 1) * D + k] = sb;
+                    } else {
+                        atomicAdd(&dw[k], sw);
+                        atomicAdd(&db[k], sb);
+                    }
                 }
             }
         }
     }
+}
+
+// out_a[k] += sum_b part[b][0][k], out_b[k] += sum_b part[b][1][k] in block order (bitwise repeatable; float atomics are not)
+__global__ void reduce_pairs_kernel(const float* __restrict__ part, int nblocks, int D, float* __restrict__ out_a,
+                                    float* __restrict__ out_b) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 2 * D) return;
+    const int which = k / D, col = k - which * D;
+    float acc = 0.f;
+    for (int b = 0; b < nblocks; ++b) acc += part[((int64_t)b * 2 + which) * D + col];
+    float* o = which ? out_b : out_a;
+    o[col] += acc;
+}
+
+// out[n] += sum_y part[y][n] in row-block order
+__global__ void reduce_rows_kernel(const float* __restrict__ part, int ny, int N, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int y = 0; y < ny; ++y) acc += part[(int64_t)y * N + n];
+    out[n] += acc;
 }
 
 // ---------------------------------------------------------------------------------------------- max-pool bwd
@@ -161,14 +190,15 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------- column sums
 // out[n] += sum_m src[m][n]   (bias gradients; rows split over blockIdx.y, one atomic per column per block)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ src, int64_t ld, float* __restrict__ out,
-                                                     int M, int N, int rows_per_block) {
+                                                     int M, int N, int rows_per_block, float* __restrict__ part) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const int m0 = blockIdx.y * rows_per_block;
     const int m1 = (m0 + rows_per_block < M) ? m0 + rows_per_block : M;
     float acc = 0.f;
     for (int m = m0; m < m1; ++m) acc += src[(int64_t)m * ld + n];
-    atomicAdd(&out[n], acc);
+    if (part) part[(int64_t)blockIdx.y * N + n] = acc;
+    else atomicAdd(&out[n], acc);
 }
 
 // dst[r][d] (+)= sum_b src[b*bs + r*ld + d]
@@ -231,13 +261,17 @@ __global__ void attn_ds_kernel(const float* __restrict__ P, float* __restrict__ 
 // ---------------------------------------------------------------------------------------------- losses
 // l1 = mean_{b,t,a} |actions - a_hat| * (1 - is_pad)   (policy.py:314-315: mean over ALL elements)
 __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ a_hat, const float* __restrict__ actions,
-                                                      const uint8_t* __restrict__ is_pad, float* __restrict__ losses,
+                                                      const uint8_t* __restrict__ is_pad, float* __restrict__ part,
                                                       int A, int64_t total) {
     float acc = 0.f;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x)
         if (!is_pad[idx / A]) acc += fabsf(actions[idx] - a_hat[idx]);
     acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&losses[0], acc / (float)total);
+    __shared__ float s_w[4];
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    // one partial per block (summed in block order by loss_total_kernel: the loss is bitwise repeatable)
+    if (threadIdx.x == 0) part[blockIdx.x] = ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])) / (float)total;
 }
 
 // kl = mean_b sum_d -0.5 (1 + logvar - mu^2 - exp(logvar))   (policy.py:386-387)
@@ -255,7 +289,12 @@ __global__ void kl_loss_kernel(const float* __restrict__ latent_info, float* __r
     if (threadIdx.x == 0) losses[1] = (part[0] + part[1] + part[2] + part[3]) / (float)B;
 }
 
-__global__ void loss_total_kernel(float* losses, float kl_weight) { losses[2] = losses[0] + losses[1] * kl_weight; }
+__global__ void loss_total_kernel(float* losses, const float* __restrict__ part, int nparts, float kl_weight) {
+    float l1 = 0.f;
+    for (int i = 0; i < nparts; ++i) l1 += part[i];
+    losses[0] = l1;
+    losses[2] = l1 + losses[1] * kl_weight;
+}
 
 // d a_hat = sign(a_hat - actions) * (1 - is_pad) / (B*Q*A) * gscale
 __global__ void l1_bwd_kernel(const float* __restrict__ a_hat, const float* __restrict__ actions,
@@ -416,16 +455,18 @@ int launch_attn_ds_drop(const float* P, float* dP, const float* delta, float sca
 }
 
 int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* dx_add, float* dx, float* dw, float* db,
-                  int M, int D, float eps, hipStream_t st) {
+                  int M, int D, float eps, hipStream_t st, float* ws, int64_t ws_floats) {
     if ((D & 3) || D > 64 * 4 * MAXV) return -2;
     if (M <= 0) return 0;
     // persistent workgroups (each adds its dw/db partials once): 4 per CU -- with one wave per SIMD (256 workgroups) the
     // dependent load -> reduce -> store chain of a row ran at 0.5 TB/s
     int blocks = (M + 3) / 4;
     if (blocks > 1024) blocks = 1024;
+    // with a workspace the dw / db partials of the blocks are summed in a fixed order (bitwise repeatable gradients)
+    float* part = (ws && (int64_t)blocks * 2 * D <= ws_floats) ? ws : nullptr;
     prof_begin("ln_bwd_kernel", 0.0, 4.0 * M * D * 3.0, st);
     const int nv = (D / 4 + 63) / 64;
-#define ACTMI_LNB(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(blocks), dim3(256), 0, st, x, w, dy, dx_add, dx, dw, db, M, D, eps)
+#define ACTMI_LNB(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(blocks), dim3(256), 0, st, x, w, dy, dx_add, dx, dw, db, M, D, eps, part)
     switch (nv) {
         case 1: ACTMI_LNB(1); break;
         case 2: ACTMI_LNB(2); break;
@@ -434,6 +475,7 @@ int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* 
         default: ACTMI_LNB(MAXV); break;
     }
 #undef ACTMI_LNB
+    if (part) hipLaunchKernelGGL(reduce_pairs_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, part, blocks, D, dw, db);
     prof_end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -498,12 +540,14 @@ int launch_maxpool_bwd(const float* x, const float* dy, float* dx, int nimg, int
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int launch_colsum(const float* src, int64_t ld, float* out, int M, int N, hipStream_t st) {
+int launch_colsum(const float* src, int64_t ld, float* out, int M, int N, hipStream_t st, float* ws, int64_t ws_floats) {
     if (M <= 0 || N <= 0) return 0;
     int rpb = 256;
     dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
+    float* part = (ws && grid.y > 1 && (int64_t)grid.y * N <= ws_floats) ? ws : nullptr;      // one row block: already ordered
     prof_begin("colsum_kernel", 0.0, 4.0 * M * N, st);
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, src, ld, out, M, N, rpb);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, src, ld, out, M, N, rpb, part);
+    if (part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, (int)grid.y, N, out);
     prof_end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -552,9 +596,9 @@ int launch_losses(const float* a_hat, const float* actions, const uint8_t* is_pa
     const int64_t total = (int64_t)B * Q * A;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(l1_loss_kernel, dim3(blocks), dim3(256), 0, st, a_hat, actions, is_pad, losses, A, total);
+    hipLaunchKernelGGL(l1_loss_kernel, dim3(blocks), dim3(256), 0, st, a_hat, actions, is_pad, losses + 4, A, total);
     if (latent_info) hipLaunchKernelGGL(kl_loss_kernel, dim3(1), dim3(256), 0, st, latent_info, losses, B, L);
-    hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, st, losses, kl_weight);
+    hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, st, losses, losses + 4, blocks, kl_weight);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -116,11 +116,12 @@ void prof_begin(const char* name, double flops, double bytes, hipStream_t st);
 void prof_end(hipStream_t st);
 
 // ---- backward-pass kernels (bwd.hip, misc.hip) ---------------------------------------------------------
+// ws (optional): scratch for the deterministic form -- per-block dw / db partials summed in block order instead of float atomics
 int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* dx_add, float* dx, float* dw, float* db,
-                  int M, int D, float eps, hipStream_t st);
+                  int M, int D, float eps, hipStream_t st, float* ws = nullptr, int64_t ws_floats = 0);
 int launch_maxpool_bwd(const float* x, const float* dy, float* dx, int nimg, int H, int W, int C, int Ho, int Wo,
                        hipStream_t st);
-int launch_colsum(const float* src, int64_t ld, float* out, int M, int N, hipStream_t st);
+int launch_colsum(const float* src, int64_t ld, float* out, int M, int N, hipStream_t st, float* ws = nullptr, int64_t ws_floats = 0);
 int launch_sum_batch(const float* src, int64_t bs, int64_t ld, float* dst, int B, int R, int D, int accumulate,
                      hipStream_t st);
 int launch_attn_delta(const float* dO, const float* O, float* delta, int B, int H, int Nq, int HD, hipStream_t st);
@@ -128,6 +129,7 @@ int launch_attn_probs(float* S, const float* lse, const uint8_t* kpm, int64_t kp
                       hipStream_t st);
 int launch_attn_ds(const float* P, float* dP, const float* delta, float scale, int G, int Nq, int Nk, int ldp,
                    hipStream_t st);
+// losses: [3] results followed by >= 513 floats of scratch (block partials of the l1 sum: fixed-order total)
 int launch_losses(const float* a_hat, const float* actions, const uint8_t* is_pad, const float* latent_info, float* losses,
                   int B, int Q, int A, int L, float kl_weight, hipStream_t st);
 int launch_bcast_add_rows(float* dst, const float* vec, int R, int D, hipStream_t st);

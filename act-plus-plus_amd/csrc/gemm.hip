@@ -62,7 +62,10 @@ __device__ __forceinline__ int swz_row(int r) { return r ^ ((r >> 3) & 3); }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC, int BSPLIT>
+// UNMASKED (f16x3, forward operand forms only): the loop flavour without zero-fill selects and operand pre-scales is
+// its own instantiation -- as a block-uniform branch inside one kernel both flavours shared one register allocation and the
+// hot one spilled (A_N: 184 bytes of scratch per lane, A_NADD: 104)
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC, int BSPLIT, int UNMASKED>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128 * 64 && (AMODE == 0 /*A_N*/ || AMODE == 3 /*A_T*/) && !(AMODE == 0 && BMODE == 1)) ? 3 : 2)
     void gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;      // 256 threads (4 waves) or 512 (8 waves, 2 per SIMD) for the 256x128 tile
@@ -600,9 +603,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                 __syncthreads();
             }
         };
-        // block-uniform choice of the loop flavour
-        if ((AMODE == A_N || AMODE == A_NADD || AMODE == A_CONV) && BMODE == B_N && (p.K % BK) == 0 && pre_a == 1.f && pre_b == 1.f)
-            run(std::false_type{});
+        // the loop flavour is chosen on the host (launch_cfg): UNMASKED needs K % 32 == 0 and no operand pre-scales
+        if constexpr (UNMASKED != 0) run(std::false_type{});
         else run(std::true_type{});
     } else {
     load_tile(kt_begin, R0);
@@ -848,12 +850,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
     if (stamp && threadIdx.x == 0) stamp[3] = __builtin_amdgcn_s_memtime();
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC, int BSPLIT>
-int launch_cfg_b(const GemmArgs& a, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC, int BSPLIT, int UNMASKED>
+int launch_cfg_u(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     static const int lds_pad = getenv("ACTMI_GEMM_LDSPAD") ? atoi(getenv("ACTMI_GEMM_LDSPAD")) : 0;   // tuning aid
     const int smem = 2 * stage_f4<BM, BN, PREC>() * 16 + lds_pad;
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT>;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, UNMASKED>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -884,6 +886,17 @@ int launch_cfg_b(const GemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, dim3((BM / WM) * (BN / WN) * 64), smem, st, a, tiles_m, tiles_n);
     prof_end(st);
     return (int)hipGetLastError();
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC, int BSPLIT>
+int launch_cfg_b(const GemmArgs& a, hipStream_t st) {
+    constexpr bool HOT = PREC == PREC_F16X3 && BMODE == B_N && (AMODE == A_N || AMODE == A_NADD || AMODE == A_CONV);
+    if constexpr (HOT) {
+        const bool one_a = (a.a_scale == 0.f || a.a_scale == 1.f) && !a.a_scale_dev;
+        const bool one_b = BSPLIT || ((a.b_scale == 0.f || a.b_scale == 1.f) && !a.b_scale_dev);
+        if ((a.K % BK) == 0 && one_a && one_b) return launch_cfg_u<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, 1>(a, st);
+    }
+    return launch_cfg_u<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, 0>(a, st);
 }
 
 template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC>

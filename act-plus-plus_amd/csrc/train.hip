@@ -57,7 +57,45 @@ GemmArgs G0() {
 int tgemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
     if (a.ta == 0 && a.tb == 0 && a.mode != 2) return ctx_gemm(ctx, a, st);
     a.prec = ctx->gemm_prec;
+    TrainState* T = ctx->train;
+    if (a.splitk > 1 && a.split_stride == 0 && T && T->det_ws && !a.rowmap && !a.C2 && !a.mask && a.groups_inner == 0) {
+        // C += A B with the contraction split over the grid.  The atomic form (every split adds into C) is not run-to-run
+        // repeatable; here every split stores a plain slice and a second kernel adds the slices to C in split order.
+        const int groups = a.groups > 0 ? a.groups : 1;
+        const int nk = (a.K + 31) / 32;
+        int S = a.splitk;
+        while (S >= 2 && (S - 1) * ((nk + S - 1) / S) >= nk) --S;              // every split must own a K tile
+        const int64_t slice = (int64_t)a.M * a.N;
+        while (S >= 2 && slice * groups * S > T->det_ws_floats) --S;
+        if (S >= 2 && (a.N & 3) == 0) {
+            GemmArgs p = a;
+            p.C = T->det_ws; p.ldc = a.N; p.gC = slice * S;
+            p.splitk = S; p.split_stride = slice;
+            p.res = nullptr;
+            int rc = launch_gemm(p, st, &ctx->err);
+            if (rc) return rc;
+            SplitCombineArgs c{};
+            c.part = T->det_ws; c.nsplit = S; c.split_stride = slice; c.gP = slice * S; c.ldp = a.N;
+            c.res = a.C; c.ldres = a.ldc; c.gRes = a.gC;                        // accumulate: C = C + sum of slices
+            c.C = a.C; c.ldc = a.ldc; c.gC = a.gC;
+            c.M = a.M; c.N = a.N; c.groups = groups;
+            rc = launch_splitk_combine(c, st);
+            if (rc) ctx->err = "splitk combine launch failed";
+            return rc;
+        }
+        a.splitk = 0;                                   // cannot slice: one pass over the whole contraction, C += through res
+        a.res = a.C; a.ldres = a.ldc; a.gRes = a.gC;
+    }
     return launch_gemm(a, st, &ctx->err);
+}
+
+// LayerNorm backward / column sums with their partials summed in a fixed order (TrainState::det_ws)
+int ln_bwd_d(actmi_ctx* ctx, const float* x, const float* w, const float* dy, const float* dx_add, float* dx, float* dw, float* db,
+             int M, int D, float eps, hipStream_t st) {
+    return launch_ln_bwd(x, w, dy, dx_add, dx, dw, db, M, D, eps, st, ctx->train->det_ws, ctx->train->det_ws_floats);
+}
+int colsum_d(actmi_ctx* ctx, const float* src, int64_t ld, float* out, int M, int N, hipStream_t st) {
+    return launch_colsum(src, ld, out, M, N, st, ctx->train->det_ws, ctx->train->det_ws_floats);
 }
 
 // Gradient operands of the f16x3 backward GEMMs get a power-of-two scale computed on the device from their largest
@@ -130,7 +168,7 @@ int lin_wgrad(actmi_ctx* ctx, const float* dy, int64_t lddy, int M, int N, const
         a.a_scale_dev = dyn_scale(ctx, dy, lddy, M, N, st);
         CHK(tgemm(ctx, a, st));
     }
-    if (db) CHK(launch_colsum(dy, lddy, db, M, N, st));
+    if (db) CHK(colsum_d(ctx, dy, lddy, db, M, N, st));
     return 0;
 }
 
@@ -244,7 +282,7 @@ int enc_bwd(actmi_ctx* ctx, const EncW& w, const EncSave& s, const float* dOut, 
     const bool drop = dr.p > 0.f;
     const float inv_keep = drop ? 1.f / (1.f - dr.p) : 1.f;
     // norm2:  Y2 = X1 + drop3(linear2(Hb))
-    CHK(launch_ln_bwd(s.Y2, w.n2w, dOut, nullptr, gA, Gp(w.n2w), Gp(w.n2b), M, D, 1e-5f, st));             // gA = dY2
+    CHK(ln_bwd_d(ctx, s.Y2, w.n2w, dOut, nullptr, gA, Gp(w.n2w), Gp(w.n2b), M, D, 1e-5f, st));             // gA = dY2
     const float* dz2 = gA;
     if (drop) { CHK(launch_dropout_bwd(gA, gC, dr.s(3), dr.p, (int64_t)M * D, st)); dz2 = gC; }
     // linear2 / dropout / relu / linear1:  Hb = drop2(relu(linear1(X1))); dropped or negative entries are 0 in Hb
@@ -253,7 +291,7 @@ int enc_bwd(actmi_ctx* ctx, const EncW& w, const EncSave& s, const float* dOut, 
     CHK(lin_dgrad(ctx, gH, F, M, F, w.l1w, D, gC, D, gA, nullptr, st));                                      // gC = dX1
     CHK(lin_wgrad(ctx, gH, F, M, F, s.X1, D, D, nullptr, 0, Gp(w.l1w), Gp(w.l1b), st));
     // norm1:  Y1 = x_in + drop1(out_proj(ATT))
-    CHK(launch_ln_bwd(s.Y1, w.n1w, gC, nullptr, gA, Gp(w.n1w), Gp(w.n1b), M, D, 1e-5f, st));               // gA = dY1
+    CHK(ln_bwd_d(ctx, s.Y1, w.n1w, gC, nullptr, gA, Gp(w.n1w), Gp(w.n1b), M, D, 1e-5f, st));               // gA = dY1
     const float* dz1 = gA;
     if (drop) { CHK(launch_dropout_bwd(gA, gC, dr.s(1), dr.p, (int64_t)M * D, st)); dz1 = gC; }
     float* dATT = gH;                                                                                        // [M][D] view
@@ -274,7 +312,7 @@ int enc_bwd(actmi_ctx* ctx, const EncW& w, const EncSave& s, const float* dOut, 
     CHK(lin_dgrad(ctx, gQKV, 3 * D, M, 3 * D, w.attn.in_w, D, dIn, D, gA, nullptr, st));
     CHK(lin_wgrad(ctx, gQKV, 3 * D, M, 2 * D, s.x_in, D, D, pos, n, Gp(w.attn.in_w), nullptr, st));
     CHK(lin_wgrad(ctx, gQKV + 2 * D, 3 * D, M, D, s.x_in, D, D, nullptr, 0, Gp(w.attn.in_w) + (int64_t)2 * D * D, nullptr, st));
-    CHK(launch_colsum(gQKV, 3 * D, Gp(w.attn.in_b), M, 3 * D, st));
+    CHK(colsum_d(ctx, gQKV, 3 * D, Gp(w.attn.in_b), M, 3 * D, st));
     if (dpos2) {
         // additional_pos_embed rows: d(x+pos)[b][j] = dQK[b][j] W_in[0:2D], summed over the batch, j in {0,1}
         GemmArgs a = G0();
@@ -384,6 +422,10 @@ int train_create(actmi_ctx* ctx) {
         T.pool_arg = reinterpret_cast<uint8_t*>(pa);
     }
     TA(T.scale_slots, 2 * SCALE_SLOTS);
+    // deterministic reductions: slices of split weight-gradient contractions and per-block partials of the LayerNorm /
+    // bias-gradient sums, all combined in a fixed order (no float atomics: gradients are bitwise repeatable)
+    T.det_ws_floats = (int64_t)48 << 20;
+    TA(T.det_ws, T.det_ws_floats);
     if (hipMemset(T.scale_slots, 0, 2 * SCALE_SLOTS * 4) != hipSuccess) { ctx->err = "hipMemset failed"; return ACTMI_E_LAUNCH; }
     // transformer saves
     auto alloc_enc = [&](std::vector<EncSave>& v, int n, float* first_in) -> int {
@@ -420,7 +462,7 @@ int train_create(actmi_ctx* ctx) {
     TA(T.dqB, BQ * D); TA(T.gT1, BQ * D); TA(T.dsaB, BQ * D); TA(T.dqkB, BQ * 2 * D); TA(T.dvB, BQ * D); TA(T.dqk_d, (int64_t)Q * 2 * D);
     TA(T.tmpQD, (int64_t)Q * D);
     { float* t; TA(t, (BQ + 3) / 4 + 1); T.is_pad = reinterpret_cast<uint8_t*>(t); }
-    TA(T.losses, 4);
+    TA(T.losses, 4 + 520);               // [l1, kl, loss, -] + block partials of the l1 sum (launch_losses)
     // backward scratch
     const int64_t MN = (int64_t)B * N;
     TA(T.gA, MN * D); TA(T.gB, MN * D); TA(T.gC, MN * D); TA(T.gH, MN * F); TA(T.gQKV, MN * 3 * D);
@@ -671,10 +713,10 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
     CHK(lin_wgrad(ctx, d_ahat, A, M, A, T.hs, D, D, nullptr, 0, GP("action_head.weight"), GP("action_head.bias"), st));
     // decoder.norm, norm3
     float* dT3 = T.gC;
-    CHK(launch_ln_bwd(T.T3, ctx->P("transformer.decoder.norm.weight"), dhs, nullptr, dT3, GP("transformer.decoder.norm.weight"),
+    CHK(ln_bwd_d(ctx, T.T3, ctx->P("transformer.decoder.norm.weight"), dhs, nullptr, dT3, GP("transformer.decoder.norm.weight"),
                       GP("transformer.decoder.norm.bias"), M, D, 1e-5f, st));
     float* dY3 = T.gA;
-    CHK(launch_ln_bwd(T.Y3pre, d.n3w, dT3, nullptr, dY3, Gp(d.n3w), Gp(d.n3b), M, D, 1e-5f, st));
+    CHK(ln_bwd_d(ctx, T.Y3pre, d.n3w, dT3, nullptr, dY3, Gp(d.n3w), Gp(d.n3b), M, D, 1e-5f, st));
     const float dp = T.drop_p;
     const bool gen = dp > 0.f;
     const Drop dr_dec{dp, T.drop_seed, 200};
@@ -689,7 +731,7 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
     CHK(lin_wgrad(ctx, T.gH, F, M, F, T.T2, D, D, nullptr, 0, Gp(d.l1w), Gp(d.l1b), st));
     // norm2:  Y2pre = t1 + drop2(out_proj(Oc))
     float* dY2 = T.gA;
-    CHK(launch_ln_bwd(T.Y2pre, d.n2w, dT2, nullptr, dY2, Gp(d.n2w), Gp(d.n2b), M, D, 1e-5f, st));
+    CHK(ln_bwd_d(ctx, T.Y2pre, d.n2w, dT2, nullptr, dY2, Gp(d.n2w), Gp(d.n2b), M, D, 1e-5f, st));
     const float* dz2 = dY2;
     if (gen) { CHK(launch_dropout_bwd(dY2, T.gC, dr_dec.s(5), dp, (int64_t)M * D, st)); dz2 = T.gC; }
     float* dOc = T.gH;                      // [M][D] view of the big scratch
@@ -697,7 +739,7 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
     CHK(lin_wgrad(ctx, dz2, D, M, D, T.Oc, D, D, nullptr, 0, Gp(d.cross.out_w), Gp(d.cross.out_b), st));
     float* dt1 = T.tmpD;                    // [D]  (constant path: t1 is one broadcast row)
     HIPCHK(hipMemsetAsync(T.tmpD, 0, 4 * D * sizeof(float), st));
-    if (!gen) CHK(launch_colsum(dY2, D, dt1, M, D, st));
+    if (!gen) CHK(colsum_d(ctx, dY2, D, dt1, M, D, st));
     else HIPCHK(hipMemcpyAsync(T.gT1, dY2, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));     // residual branch: dT1 = dY2
     // cross attention
     float* dKV = T.gQKV;                    // [B*N][2D]
@@ -723,10 +765,10 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
         CHK(lin_dgrad(ctx, ddq, D, Q, D, d.cross.in_w, D, dqin, D, nullptr, nullptr, st));
         CHK(lin_wgrad(ctx, ddq, D, Q, D, T.qin, D, D, nullptr, 0, Gp(d.cross.in_w), Gp(d.cross.in_b), st));
         CHK(launch_axpy(GP("query_embed.weight"), dqin, (int64_t)Q * D, st));
-        CHK(launch_colsum(dqin, D, dt1, Q, D, st));
+        CHK(colsum_d(ctx, dqin, D, dt1, Q, D, st));
         // t1 = norm1(out_proj(b_v) + b_o)
         float* dsa = T.tmpD + D;
-        CHK(launch_ln_bwd(T.sa_tmp, d.n1w, dt1, nullptr, dsa, Gp(d.n1w), Gp(d.n1b), 1, D, 1e-5f, st));
+        CHK(ln_bwd_d(ctx, T.sa_tmp, d.n1w, dt1, nullptr, dsa, Gp(d.n1w), Gp(d.n1b), 1, D, 1e-5f, st));
         float* dbv = T.tmpD + 2 * D;
         CHK(lin_dgrad(ctx, dsa, D, 1, D, d.self_attn.out_w, D, dbv, D, nullptr, nullptr, st));
         CHK(lin_wgrad(ctx, dsa, D, 1, D, d.self_attn.in_b + 2 * D, D, D, nullptr, 0, Gp(d.self_attn.out_w), Gp(d.self_attn.out_b), st));
@@ -739,7 +781,7 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
         CHK(launch_sum_batch(dqin, (int64_t)Q * D, D, GP("query_embed.weight"), B, Q, D, 1, st));
         CHK(launch_axpy(T.gT1, dqin, (int64_t)M * D, st));
         // T1 = norm1(drop1(out_proj(sO)))
-        CHK(launch_ln_bwd(T.saB, d.n1w, T.gT1, nullptr, T.dsaB, Gp(d.n1w), Gp(d.n1b), M, D, 1e-5f, st));
+        CHK(ln_bwd_d(ctx, T.saB, d.n1w, T.gT1, nullptr, T.dsaB, Gp(d.n1w), Gp(d.n1b), M, D, 1e-5f, st));
         CHK(launch_dropout_bwd(T.dsaB, T.gT1, dr_dec.s(1), dp, (int64_t)M * D, st));            // gT1 := d(out_proj output)
         float* dsO = T.gA;
         CHK(lin_dgrad(ctx, T.gT1, D, M, D, d.self_attn.out_w, D, dsO, D, nullptr, nullptr, st));
@@ -757,7 +799,7 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
         t.B = B; t.H = H; t.Nq = Q; t.Nk = Q; t.HD = hd;
         t.drop_p = dp; t.drop_seed = dr_dec.s(0);
         CHK(attn_bwd(ctx, t, st));
-        CHK(launch_colsum(T.dvB, D, Gp(d.self_attn.in_b) + 2 * D, M, D, st));                     // d b_v (sum over keys and batch)
+        CHK(colsum_d(ctx, T.dvB, D, Gp(d.self_attn.in_b) + 2 * D, M, D, st));                     // d b_v (sum over keys and batch)
         CHK(launch_sum_batch(T.dqkB, (int64_t)Q * 2 * D, 2 * D, T.dqk_d, B, Q, 2 * D, 0, st));    // q/k are shared over the batch
         CHK(lin_dgrad(ctx, T.dqk_d, 2 * D, Q, 2 * D, d.self_attn.in_w, D, T.tmpQD, D, nullptr, nullptr, st));
         CHK(launch_axpy(GP("query_embed.weight"), T.tmpQD, (int64_t)Q * D, st));
@@ -769,7 +811,7 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
     CHK(lin_dgrad(ctx, dKV, 2 * D, B * N, 2 * D, d.cross.in_w + (int64_t)D * D, D, dmem, D, nullptr, nullptr, st));
     CHK(lin_wgrad(ctx, dKV, 2 * D, B * N, D, T.mem, D, D, ctx->pos_tokens, N, Gp(d.cross.in_w) + (int64_t)D * D, nullptr, st));
     CHK(lin_wgrad(ctx, dKV + D, 2 * D, B * N, D, T.mem, D, D, nullptr, 0, Gp(d.cross.in_w) + (int64_t)2 * D * D, nullptr, st));
-    CHK(launch_colsum(dKV, 2 * D, Gp(d.cross.in_b) + D, B * N, 2 * D, st));
+    CHK(colsum_d(ctx, dKV, 2 * D, Gp(d.cross.in_b) + D, B * N, 2 * D, st));
     float* dpos2 = GP("additional_pos_embed.weight");
     {
         GemmArgs a = G0();
@@ -787,14 +829,14 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
     float* dX = T.gB;                       // grad wrt the token matrix [B][N][D]
     // token 1: proprio = W_s qpos + b_s
     CHK(launch_small_linear_wgrad(dX + D, (int64_t)N * D, T.qpos, S, GP("input_proj_robot_state.weight"), B, D, S, st));
-    CHK(launch_colsum(dX + D, (int64_t)N * D, GP("input_proj_robot_state.bias"), B, D, st));
+    CHK(colsum_d(ctx, dX + D, (int64_t)N * D, GP("input_proj_robot_state.bias"), B, D, st));
     // token 0: latent_input = W_lo z + b_lo
     if (g.has_cvae_encoder) {
         const int Lz = g.vq ? g.vq_class * g.vq_dim : L;
         CHK(launch_small_linear_wgrad(dX, (int64_t)N * D, T.z, Lz, GP("latent_out_proj.weight"), B, D, Lz, st));
         CHK(lin_dgrad(ctx, dX, (int64_t)N * D, B, D, ctx->P("latent_out_proj.weight"), Lz, T.dz, Lz, nullptr, nullptr, st));
     }
-    CHK(launch_colsum(dX, (int64_t)N * D, GP("latent_out_proj.bias"), B, D, st));
+    CHK(colsum_d(ctx, dX, (int64_t)N * D, GP("latent_out_proj.bias"), B, D, st));
     // tokens 2..: input_proj (1x1 conv) of the layer4 maps
     const int MP = C * B * ctx->P_;
     CHK(launch_gather_rows(dX, ctx->rowmap, T.dXg, MP, D, st));
@@ -882,7 +924,7 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
         float* dXc = T.gB;
         CHK(launch_sum_batch(dXc, (int64_t)n * D, D, GP("cls_embed.weight"), B, 1, D, 1, st));
         CHK(launch_small_linear_wgrad(dXc + D, (int64_t)n * D, T.qpos, S, GP("encoder_joint_proj.weight"), B, D, S, st));
-        CHK(launch_colsum(dXc + D, (int64_t)n * D, GP("encoder_joint_proj.bias"), B, D, st));
+        CHK(colsum_d(ctx, dXc + D, (int64_t)n * D, GP("encoder_joint_proj.bias"), B, D, st));
         CHK(launch_gather_rows(dXc, T.cmap, T.dXg, B * Q, D, st));
         CHK(lin_wgrad(ctx, T.dXg, D, B * Q, D, T.actions, A, A, nullptr, 0, GP("encoder_action_proj.weight"),
                       GP("encoder_action_proj.bias"), st));

@@ -265,9 +265,11 @@ def sub_record(cfg, B, dev, steps, warmup, prec=None, note=""):
     dom, ach = dominant(prof)
     lat = latency(rig, 30)
     assert rig.torch.isfinite(rig.output()).all()
+    rig.eng.check_flags()
+    graphed = rig.graphed
     rig.close()
     return {"per_gpu_batch": B, "steps": steps, "ms_per_step": dt / steps * 1e3, "policy_steps_per_s": B * steps / dt,
-            "step_latency_ms": lat, "launch": "hipGraph replay" if rig.graphed else "eager",
+            "step_latency_ms": lat, "launch": "hipGraph replay" if graphed else "eager",
             "dominant_kernel": dom["name"], "dominant_tflops": ach, "dominant_frac": ach / kernel_peak(dom["name"])[0],
             "dominant_share": dom["ms"] / gpu_ms, "note": note}
 
@@ -319,6 +321,7 @@ def bench_infer(args, cfg, B, ctx):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(rig.output()).all()
+    rig.eng.check_flags()              # default-on range guard of the f16x3 arithmetic (reads the device flag word)
 
     # sustained leg: >= args.sustained_s of back-to-back steps (every rank runs it; max over ranks)
     sustained = None
