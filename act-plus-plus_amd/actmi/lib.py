@@ -125,6 +125,12 @@ def load():
         "actmi_op_maxpool3x3s2": ([vp, vp, i32, i32, i32, i32, vp], i32),
         "actmi_op_conv1": ([vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
         "actmi_op_conv3x3_c64": ([vp, vp, C.c_float, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+        "actmi_op_groupnorm": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp], i32),
+        "actmi_op_spatial_softmax": ([vp, vp, i32, i32, i32, i32, f32, vp], i32),
+        "actmi_op_unfold1d": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+        "actmi_op_ddim_step": ([vp, vp, C.c_int64, f32, f32, f32, f32, i32, vp], i32),
+        "actmi_op_mish": ([vp, vp, C.c_int64, vp], i32),
+        "actmi_op_u8_to_nhwc4": ([vp, vp, i32, i32, i32, i32, vp], i32),
         "actmi_op_last_error": ([], C.c_char_p),
         "actmi_debug_tensor": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i64)], i32),
         "actmi_debug_stop_after": ([vp, C.c_char_p], i32),

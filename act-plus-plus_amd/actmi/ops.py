@@ -291,6 +291,78 @@ def conv1(image, w_oihw, scale, bias, prec=None):
     return out
 
 
+# ---- DiffusionPolicy path (reference policy.py:20-241): the non-GEMM ops, channel-last ---------------------------------
+ACT = {None: 0, "none": 0, "relu": 1, "mish": 2}
+
+
+def groupnorm(x, weight, bias, groups, eps=1e-5, act=None, res=None, res_after=False, film=None):
+    """x [n, P, C] (any leading spatial shape flattened into P is fine: pass [n, ..., C]); torch.nn.GroupNorm statistics.
+    out = act(GN(x) + res) (res_after=False) or act(GN(x)) * film_scale + film_bias + res (res_after=True)."""
+    lib = L.load()
+    x = x.contiguous()
+    n, Cc = x.shape[0], x.shape[-1]
+    P = x.numel() // (n * Cc)
+    out = torch.empty_like(x)
+    fs, fb = (film[0].contiguous(), film[1].contiguous()) if film is not None else (None, None)
+    rm = 0 if res is None else (2 if res_after else 1)
+    L.check(lib.actmi_op_groupnorm(_p(x), _p(res.contiguous() if res is not None else None), _p(fs), _p(fb), _p(weight), _p(bias),
+                                   _p(out), n, P, Cc, int(groups), float(eps), ACT[act], rm, L.current_stream_ptr()), None,
+            "op_groupnorm")
+    return out
+
+
+def spatial_softmax(logits, H, W, temperature=1.0):
+    """logits [n, H*W, K] -> [n, K, 2] expected (x, y) keypoints (robomimic SpatialSoftmax)."""
+    lib = L.load()
+    logits = logits.contiguous()
+    n, P, K = logits.shape
+    assert P == H * W
+    out = torch.empty((n, K, 2), dtype=torch.float32, device=logits.device)
+    L.check(lib.actmi_op_spatial_softmax(_p(logits), _p(out), n, H, W, K, float(temperature), L.current_stream_ptr()), None,
+            "op_spatial_softmax")
+    return out
+
+
+def unfold1d(x, k, stride=1, pad=0, transposed=False):
+    """x [B, T, C] -> [B, To, k*C]: the rows a Conv1d (or, transposed, a ConvTranspose1d) contracts with its weights."""
+    lib = L.load()
+    x = x.contiguous()
+    B, T, Cc = x.shape
+    To = (T - 1) * stride - 2 * pad + k if transposed else (T + 2 * pad - k) // stride + 1
+    out = torch.empty((B, To, k * Cc), dtype=torch.float32, device=x.device)
+    L.check(lib.actmi_op_unfold1d(_p(x), _p(out), B, T, Cc, k, stride, pad, To, 1 if transposed else 0, L.current_stream_ptr()),
+            None, "op_unfold1d")
+    return out
+
+
+def ddim_step(x, eps, alpha_t, alpha_prev, clip=True):
+    """in place: diffusers DDIMScheduler.step with eta = 0, epsilon prediction."""
+    lib = L.load()
+    assert x.is_contiguous() and eps.is_contiguous() and x.numel() == eps.numel()
+    L.check(lib.actmi_op_ddim_step(_p(x), _p(eps), x.numel(), float(alpha_t ** -0.5), float((1.0 - alpha_t) ** 0.5),
+                                   float(alpha_prev ** 0.5), float(max(0.0, 1.0 - alpha_prev) ** 0.5), 1 if clip else 0,
+                                   L.current_stream_ptr()), None, "op_ddim_step")
+    return x
+
+
+def mish(x):
+    lib = L.load()
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    L.check(lib.actmi_op_mish(_p(x), _p(y), x.numel(), L.current_stream_ptr()), None, "op_mish")
+    return y
+
+
+def u8_to_nhwc4(image_u8):
+    """u8 [B, Cam, H, W, 3] -> f32 [Cam, B, H, W, 4] in [0, 1] (channel 3 = 0): the GEMM convolution wants Cin % 4 == 0."""
+    lib = L.load()
+    image_u8 = image_u8.contiguous()
+    B, Cam, H, W, _ = image_u8.shape
+    out = torch.empty((Cam, B, H, W, 4), dtype=torch.float32, device=image_u8.device)
+    L.check(lib.actmi_op_u8_to_nhwc4(_p(image_u8), _p(out), B, Cam, H, W, L.current_stream_ptr()), None, "op_u8_to_nhwc4")
+    return out
+
+
 class TemporalEnsemble:
     """Batched temporal ensembling state for E episodes (reference imitate_episodes.py:338-339, 402-411).
     Ring buffer [E,Q,Q,A] instead of the reference's [T,T+Q,A] per episode: only the last Q chunks can

@@ -36,6 +36,9 @@ def make_policy(policy_class, policy_config, device=None):
     if policy_class == "ACT":
         from policy import ACTPolicy
         return ACTPolicy(policy_config, device=device)
+    if policy_class == "Diffusion":
+        from policy import DiffusionPolicy
+        return DiffusionPolicy(policy_config, device=device)
     raise NotImplementedError(f"policy_class {policy_class} is outside the accelerated path (SURVEY §2)")
 
 

@@ -145,3 +145,62 @@ class ACTPolicy:
         out = self.model.forward_train(qpos, img, actions, is_pad, dropout_p=0.0,
                                        dropout_seed=(self.dropout_seed << 20) + self._drop_step)
         return out["binaries"]
+
+
+class DiffusionPolicy:
+    """Drop-in for the reference's ``policy.py:DiffusionPolicy`` (policy.py:20-241) on the inference side: same constructor
+    dict (imitate_episodes.py:100-111), ``policy(qpos, image)`` -> [B, prediction_horizon, action_dim] actions, ``serialize``
+    / ``deserialize`` with the reference's {"nets", "ema"} layout (the EMA weights are what inference uses, policy.py:184-186).
+    Arithmetic in libactmi (actmi/diffusion.py); training this policy is outside the accelerated path."""
+
+    def __init__(self, args_override: dict, device: str = None, init_seed: int = 0):
+        from actmi.diffusion import DiffusionNet, generate_diffusion_state_dict
+        self.camera_names = list(args_override["camera_names"])
+        if args_override.get("use_depth", False):
+            raise NotImplementedError("depth inputs are outside the accelerated Diffusion path")
+        self.observation_horizon = args_override["observation_horizon"]
+        if self.observation_horizon != 1:
+            raise NotImplementedError("observation_horizon != 1 is marked TODO in the reference itself (policy.py:28)")
+        self.action_horizon = args_override["action_horizon"]
+        self.prediction_horizon = args_override["prediction_horizon"]
+        self.num_inference_timesteps = args_override["num_inference_timesteps"]
+        self.ema_power = args_override.get("ema_power", 0.75)
+        self.lr = args_override.get("lr", 1e-4)
+        self.ac_dim = args_override["action_dim"]
+        if device is None:
+            device = args_override.get("device") or (f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cuda:0")
+        self.model = DiffusionNet(self.camera_names, self.ac_dim, 14, self.prediction_horizon, self.num_inference_timesteps,
+                                  device=device)
+        self.model.load_state_dict(generate_diffusion_state_dict(self.model.spec, seed=init_seed))
+        self.training = False
+
+    def __call__(self, qpos, image, actions=None, is_pad=None, depth_img=None, noise=None):
+        if actions is not None:
+            raise NotImplementedError("DiffusionPolicy training is outside the accelerated path (SURVEY 8 f2): inference only")
+        if image.dtype != torch.uint8:
+            # the reference contract: f32 [B, cams, 3, H, W] in [0, 1] (imitate_episodes.py:206-225) -> the u8 NHWC fast path
+            image = (image.clamp(0, 1) * 255.0).round().to(torch.uint8).permute(0, 1, 3, 4, 2).contiguous()
+        return self.model.forward_infer(qpos, image, noise=noise)
+
+    def cuda(self):
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def configure_optimizers(self):
+        raise NotImplementedError("DiffusionPolicy training is outside the accelerated path")
+
+    def serialize(self):
+        sd = self.model.state_dict()
+        return {"nets": sd, "ema": sd}
+
+    def deserialize(self, model_dict):
+        src = model_dict.get("ema") or model_dict["nets"]          # inference runs the EMA copy (policy.py:184-186)
+        missing, unexpected = self.model.load_state_dict(src, strict=True)
+        return _LoadStatus(missing, unexpected)

@@ -394,7 +394,8 @@ def bench_infer(args, cfg, B, ctx):
                          ("b50", lambda: sub_record(cfg, 50, dev, 6, 2, note="config 2's batch (50 parallel episodes), 4 cameras")),
                          ("native_fp32", lambda: sub_record(cfg, B, dev, 10, 2, prec="f32",
                                                             note="every product on the exact fp32 MFMA (gemm_prec=f32)")),
-                         ("train_b64", lambda: train_record(cfg, 64, dev, 4, 2))):
+                         ("train_b64", lambda: train_record(cfg, 64, dev, 4, 2)),
+                         ("diffusion_b32", lambda: diffusion_record(dev, 32, 3, 1))):
             try:
                 log(f"extra.{name}")
                 extra[name] = fn()
@@ -477,6 +478,40 @@ def train_record(cfg, B, dev, steps, warmup):
             "dominant_kernel": dom["name"], "dominant_tflops": ach, "dominant_frac": ach / kernel_peak(dom["name"])[0],
             "dominant_share": dom["ms"] / gpu_ms,
             "top_kernels": [{"name": r["name"], "share": r["share"], "avg_us": r["avg_us"], "tflops": r["tflops"]} for r in rows[:6]]}
+
+
+def diffusion_record(dev, B, iters, warmup):
+    """extra.diffusion_b32 (BASELINE config 4): DiffusionPolicy batched inference, 3 cameras 480x640, prediction horizon 32,
+    the fork's DDIM schedule (10 inference steps of a 50-step scheduler, imitate_episodes.py:104, policy.py:102-109 -- the
+    config string's "100 denoise steps" is the training-step count of commands.txt:104, not what inference runs).  Restated
+    robomimic / diffusers arithmetic: parity unpinned (oracle/diffusion_ref.py)."""
+    import torch
+    from actmi import weights as W
+    from actmi.diffusion import DiffusionNet, generate_diffusion_state_dict
+    cams = ["top", "left_wrist", "right_wrist"]
+    net = DiffusionNet(cams, prediction_horizon=32, num_inference_timesteps=10, device=str(dev))
+    net.load_state_dict(generate_diffusion_state_dict(net.spec, seed=0))
+    img = torch.from_numpy(W.rand_u8(3, "dimg", (B, len(cams), 480, 640, 3))).to(dev)
+    qpos = torch.zeros((B, 14), device=dev)
+    noise = torch.randn((B, 32, 16), device=dev)
+    for _ in range(warmup):
+        out = net.forward_infer(qpos, img, noise=noise)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = net.forward_infer(qpos, img, noise=noise)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / iters
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    cond = net.obs_cond(qpos, img)
+    e0.record()
+    net.unet(noise, 45, cond)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    assert torch.isfinite(out).all()
+    return {"per_gpu_batch": B, "cameras": len(cams), "prediction_horizon": 32, "ddim_steps": 10, "ms_per_query_batch": dt * 1e3,
+            "policy_steps_per_s": B / dt, "unet_pass_ms": e0.elapsed_time(e1), "launch": "eager (op-level C ABI calls from Python)",
+            "parity": "unpinned: robomimic / diffusers restated from their published definitions (not importable offline)"}
 
 
 def bench_train(args, cfg, B, ctx):

@@ -285,6 +285,26 @@ int actmi_op_conv1(const void* image, int image_fmt, const float* w_oihw, const 
  * out = act(conv * scale + bias (+ res)) */
 int actmi_op_conv3x3_c64(const float* x, const float* w16, float w_scale, const float* scale, const float* bias,
                          const float* res, float* out, int G, int B, int H, int W, int relu, void* stream);
+/* ---- DiffusionPolicy inference path (reference policy.py:20-241, imitate_episodes.py:100-118,420-426).
+ * The non-GEMM pieces of what the reference delegates to robomimic (ResNet18Conv with BatchNorm -> GroupNorm, SpatialSoftmax,
+ * ConditionalUnet1D) and diffusers (DDIMScheduler.step); restated from the published definitions, parity unpinned (neither
+ * package is importable offline).  Channel-last tensors; dense contractions go through actmi_op_gemm.
+ * groupnorm: out = act(GN_G(x) [+ res when res_mode 1]) [* film_scale[n][c] + film_bias[n][c]] [+ res when res_mode 2];
+ *            x [n][P][C], statistics per (sample, group) over P x C/G values (torch.nn.GroupNorm); act 0 none, 1 ReLU, 2 Mish
+ * spatial_softmax: logits [n][H*W][K] -> out [n][K][2] = softmax-weighted (x, y) on the [-1, 1] grid
+ * unfold1d: x [B][T][C] -> out [B][To][k][C]; transposed = 0: rows of Conv1d(k, stride, pad); 1: gather rows of
+ *           ConvTranspose1d(k, stride, pad) (out[b][t][j] = x[b][(t + pad - j) / stride] when divisible and in range)
+ * ddim_step: in place x <- sqrt_aprev * clamp((x - sqrt_1m_at * eps) * inv_sqrt_at, -1, 1) + sqrt_1m_aprev * eps
+ * u8_to_nhwc4: u8 [B][Cam][H][W][3] -> f32 [Cam][B][H][W][4] = v / 255 (fourth channel 0) */
+int actmi_op_groupnorm(const float* x, const float* res, const float* film_scale, const float* film_bias, const float* w,
+                       const float* b, float* out, int n, int P, int C, int G, float eps, int act, int res_mode, void* stream);
+int actmi_op_spatial_softmax(const float* logits, float* out, int n, int H, int W, int K, float temperature, void* stream);
+int actmi_op_unfold1d(const float* x, float* out, int B, int T, int C, int k, int stride, int pad, int To, int transposed,
+                      void* stream);
+int actmi_op_ddim_step(float* x, const float* eps, int64_t n, float inv_sqrt_at, float sqrt_1m_at, float sqrt_aprev,
+                       float sqrt_1m_aprev, int clip, void* stream);
+int actmi_op_mish(const float* x, float* y, int64_t n, void* stream);
+int actmi_op_u8_to_nhwc4(const uint8_t* image, float* out, int B, int Cam, int H, int W, void* stream);
 const char* actmi_op_last_error(void);
 
 /* intermediate activations of the last forward (parity tests): name in {"conv1","maxpool","layer1".."layer4",
