@@ -110,6 +110,10 @@ struct actmi_ctx {
     int conv1_vpool = 1;               // inference: conv1 emits the vertical half of the max pool (ACTMI_CONV1_VPOOL=0: off)
     int fwd_splitk = 1;                // 0: never split a forward contraction (ACTMI_FWD_SPLITK=0)
     int sk_target = 1536, sk_minnk = 12, sk_maxtiles = 768;     // split heuristic (tuning aids ACTMI_FWD_SPLITK_*)
+    int sk_target_long = 4864, sk_maxtiles_long = 1300, sk_long_nk = 128;   // B = 8: very long contractions (layer4, K = 4608)
+    hipStream_t side_stream = nullptr; // downsample branch of the ResNet blocks (engine_backbone)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool ds_fork = true;
     int64_t ptotal = 0;
     bool finalized = false;
     // geometry

@@ -177,6 +177,10 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
         const int64_t tiles = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64) * groups;
         const int nk = (a.K + 31) / 32;
         int S = tiles < ctx->sk_maxtiles ? (int)((ctx->sk_target + tiles - 1) / tiles) : 1;
+        // B = 8: the 304-workgroup launches with a very long contraction (layer4's K = 4608 convolutions: 217 us unsplit,
+        // 167 us + a 26 us combine pass split four ways; the K <= 3200 shapes do not pay for their combine pass --
+        // profiles/r02_splitk_b8_sweep.json)
+        if (S == 1 && tiles < ctx->sk_maxtiles_long && nk >= ctx->sk_long_nk) S = (int)((ctx->sk_target_long + tiles - 1) / tiles);
         if (S > 8) S = 8;
         if (S > nk / ctx->sk_minnk) S = nk / ctx->sk_minnk;
         while (S >= 2 && (S - 1) * ((nk + S - 1) / S) >= nk) --S;              // every split must own a K tile
@@ -379,6 +383,7 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
         if (const char* e2 = getenv("ACTMI_FWD_SPLITK_TARGET")) ctx->sk_target = atoi(e2);
         if (const char* e2 = getenv("ACTMI_FWD_SPLITK_MINNK")) ctx->sk_minnk = atoi(e2) > 0 ? atoi(e2) : 1;
         if (const char* e2 = getenv("ACTMI_FWD_SPLITK_MAXTILES")) ctx->sk_maxtiles = atoi(e2);
+        if (const char* e2 = getenv("ACTMI_FWD_SPLITK_LONG_NK")) ctx->sk_long_nk = atoi(e2) > 0 ? atoi(e2) : 1 << 30;
         // slices of split contractions (ctx_gemm checks the fit); 256 MB covers 4-way splits of the B = 8 launches
         ctx->splitk_ws_floats = (int64_t)(getenv("ACTMI_FWD_SPLITK_WS_MB") ? atoi(getenv("ACTMI_FWD_SPLITK_WS_MB")) : 256) << 18;
         if ((rc = dev_alloc(ctx, &ctx->splitk_ws, ctx->splitk_ws_floats))) return fail(rc);
@@ -486,6 +491,19 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
         ctx->attn_ws_floats = rows * (D + 2 * g.nheads);
         if ((rc = dev_alloc(ctx, &ctx->attn_ws, ctx->attn_ws_floats))) return fail(rc);
     }
+    {
+        // second stream for the downsample branch of the ResNet blocks (ACTMI_DS_FORK=0 keeps everything on one stream).
+        // Not used while the per-launch profiler is on (its events bracket launches on one stream) or when forward
+        // contractions are being split (the side branch would share the slice workspace)
+        const char* e = getenv("ACTMI_DS_FORK");
+        ctx->ds_fork = !(e && e[0] == '0');
+        if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+            ctx->err = "cannot create the side stream";
+            return fail(ACTMI_E_LAUNCH);
+        }
+    }
     ctx->finalized = false;
     if (g.enable_training && (rc = train_create(ctx))) return fail(rc);
     *out = ctx;
@@ -495,6 +513,9 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
 int engine_destroy(actmi_ctx* ctx) {
     if (!ctx) return 0;
     for (void* p : ctx->allocs) (void)hipFree(p);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     delete ctx->train;
     delete ctx;
     return 0;
@@ -629,13 +650,13 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
     ctx->dbg["conv1"] = {ctx->act1, (int64_t)C * B * ctx->H1 * ctx->W1 * w0};
     ctx->dbg["maxpool"] = {cur, (int64_t)C * B * ctx->H2 * ctx->W2 * w0};
     if (ctx->stop_stage == "conv1" || ctx->stop_stage == "maxpool") return 1;
-    auto run_conv = [&](const ConvLayer& cl, const float* in, float* out, const float* res, int relu) -> int {
+    auto run_conv_on = [&](const ConvLayer& cl, const float* in, float* out, const float* res, int relu, hipStream_t cs) -> int {
         if (ctx->gemm_prec == ACTMI_PREC_F16X3 && cl.k == 3 && cl.stride == 1 && cl.pad == 1 && cl.cin == 64 && cl.cout == 64) {
             // layer1: direct convolution over an LDS-resident patch (the im2col GEMM is L2-traffic bound at 64 channels)
             Conv3Args c3;
             c3.x = in; c3.w16 = cl.w16; c3.scale = cl.scale; c3.bias = cl.bias; c3.res = res; c3.out = out;
             c3.G = C; c3.B = B; c3.H = cl.H; c3.W = cl.W; c3.relu = relu; c3.w_scale = cl.w16_scale;
-            return launch_conv3x3_c64(c3, st, &ctx->err);
+            return launch_conv3x3_c64(c3, cs, &ctx->err);
         }
         GemmArgs a;
         memset(&a, 0, sizeof(a));
@@ -648,20 +669,38 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
         a.groups = C;
         a.gA = (int64_t)B * cl.H * cl.W * cl.cin; a.gB = (int64_t)cl.cout * cl.K; a.gSB = cl.cout;
         a.gC = (int64_t)a.M * cl.cout; a.gRes = a.gC;
-        return ctx_gemm(ctx, a, st);
+        return ctx_gemm(ctx, a, cs);
     };
+    auto run_conv = [&](const ConvLayer& cl, const float* in, float* out, const float* res, int relu) -> int {
+        return run_conv_on(cl, in, out, res, relu, st);
+    };
+    // the side branch needs the split-K workspace for itself: only taken when the main stream's launches do not split
+    const bool fork_ds = ctx->side_stream != nullptr && ctx->ds_fork;
     size_t ci = 0;
     for (int li = 1; li <= 4; ++li) {
         for (int bi = 0; bi < 2; ++bi) {
             const ConvLayer& k1 = ctx->convs[ci++];
             const ConvLayer& k2 = ctx->convs[ci++];
             const bool has_ds = (bi == 0 && li > 1);
-            CHK(run_conv(k1, cur, s1, nullptr, 1));
             if (has_ds) {
                 const ConvLayer& ds = ctx->convs[ci++];
-                CHK(run_conv(ds, cur, s2, nullptr, 0));
+                if (fork_ds) {
+                    // the 1x1 / stride-2 downsample (23-50 us, HBM bound, few workgroups) only needs the block input: it
+                    // runs on a second stream beside the block's first 3x3 convolution (fork / join through events: in a
+                    // captured graph these are two parallel branches) and fills CUs that launch leaves idle
+                    HIPCHK(hipEventRecord(ctx->ev_fork, st));
+                    HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+                    CHK(run_conv_on(ds, cur, s2, nullptr, 0, ctx->side_stream));
+                    HIPCHK(hipEventRecord(ctx->ev_join, ctx->side_stream));
+                    CHK(run_conv(k1, cur, s1, nullptr, 1));
+                    HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+                } else {
+                    CHK(run_conv(k1, cur, s1, nullptr, 1));
+                    CHK(run_conv(ds, cur, s2, nullptr, 0));
+                }
                 CHK(run_conv(k2, s1, cur, s2, 1));       // x is dead: reuse its buffer for the block output
             } else {
+                CHK(run_conv(k1, cur, s1, nullptr, 1));
                 CHK(run_conv(k2, s1, s2, cur, 1));
                 std::swap(cur, s2);
             }
