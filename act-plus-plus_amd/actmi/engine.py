@@ -296,6 +296,34 @@ class ACTEngine:
         from .dist_utils import allreduce_buckets
         allreduce_buckets(self.grad_arena(), bucket_mb * (1 << 20) // 4, group)
 
+    def grad_phase_range(self, phase: int):
+        off, cnt = C.c_int64(), C.c_int64()
+        L.check(self.lib.actmi_grad_phase_range(self.h, int(phase), C.byref(off), C.byref(cnt)), self.h, "grad_phase_range")
+        return off.value, cnt.value
+
+    def backward_allreduce(self, loss_scale: float = 1.0, group=None, bucket_mb: int = 64):
+        """loss.backward() + data-parallel gradient averaging with the collective OVERLAPPED with the backward: the library
+        records an event once the transformer.* gradients (the head of the arena, ~45 % of it) are final; a side stream waits
+        for it and all-reduces that range in buckets (RCCL when the backend is nccl) while the backbone / CVAE-encoder backward
+        is still running on the compute stream; the remainder is reduced when the backward has drained.  Pass
+        loss_scale = 1 / world so that the sum is the mean over the global batch."""
+        import torch.distributed as dist
+        from .dist_utils import allreduce_buckets
+        self.backward(loss_scale)
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        arena = self.grad_arena()
+        lo, n = self.grad_phase_range(1)
+        cur = torch.cuda.current_stream(self.device)
+        if not hasattr(self, "_comm_stream"):
+            self._comm_stream = torch.cuda.Stream(device=self.device)
+        side = self._comm_stream
+        L.check(self.lib.actmi_wait_grad_phase(self.h, 1, C.c_void_p(side.cuda_stream)), self.h, "wait_grad_phase")
+        with torch.cuda.stream(side):
+            allreduce_buckets(arena[lo:lo + n], bucket_mb * (1 << 20) // 4, group)       # under the rest of the backward
+        allreduce_buckets(arena[lo + n:], bucket_mb * (1 << 20) // 4, group)             # after the backward has drained
+        cur.wait_stream(side)
+
     def grad(self, key: str) -> torch.Tensor:
         """Copy of the gradient of one state_dict entry (shape of the parameter)."""
         p, n = C.c_void_p(), C.c_int64()

@@ -111,6 +111,8 @@ def load():
         "actmi_adamw_step": ([vp, f32, f32, f32, f32, f32, f32, i64, vp], i32),
         "actmi_grad_ptr": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i64)], i32),
         "actmi_grad_arena": ([vp, C.POINTER(vp), C.POINTER(i64)], i32),
+        "actmi_grad_phase_range": ([vp, i32, C.POINTER(i64), C.POINTER(i64)], i32),
+        "actmi_wait_grad_phase": ([vp, i32, vp], i32),
         "actmi_ensemble_step": ([vp, vp, vp, f64, vp, vp, i32, i32, i32, vp], i32),
         "actmi_op_gemm": ([C.POINTER(GemmDesc), vp], i32),
         "actmi_op_split16": ([vp, vp, C.c_int64, C.c_float, vp], i32),

@@ -156,6 +156,28 @@ int actmi_grad_arena(actmi_handle h, void** dev_ptr, int64_t* nfloats) {
     return 0;
 }
 
+int actmi_grad_phase_range(actmi_handle h, int phase, int64_t* offset, int64_t* count) {
+    if (!h || !offset || !count || (phase != 1 && phase != 2)) return ACTMI_E_INVALID;
+    ENTER(h);
+    if (!h->train) return bad(h, "handle was created without enable_training", ACTMI_E_STATE);
+    // phase 1 = pos_table + transformer.* (registration order puts them first); everything after is phase 2
+    int64_t split = h->ptotal;
+    for (const Param& p : h->params)
+        if (p.key != "pos_table" && p.key.rfind("transformer.", 0) != 0) { split = p.off; break; }
+    *offset = phase == 1 ? 0 : split;
+    *count = phase == 1 ? split : h->ptotal - split;
+    return 0;
+}
+
+int actmi_wait_grad_phase(actmi_handle h, int phase, void* stream) {
+    if (!h || phase != 1) return ACTMI_E_INVALID;
+    ENTER(h);
+    if (!h->train || !h->train->ev_phase1) return bad(h, "handle was created without enable_training", ACTMI_E_STATE);
+    hipError_t e = hipStreamWaitEvent(S(stream), h->train->ev_phase1, 0);
+    if (e != hipSuccess) return bad(h, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e), ACTMI_E_LAUNCH);
+    return 0;
+}
+
 int actmi_ensemble_step(float* ring, int32_t* tcount, const float* chunk, double k, double* out, uint8_t* populated, int E,
                         int Q, int A, void* stream) {
     if (!ring || !tcount || !chunk || !out || Q < 1 || A < 1 || A > 64) return ACTMI_E_INVALID;

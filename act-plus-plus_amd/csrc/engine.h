@@ -71,6 +71,7 @@ struct TrainState {
     bool have_eps = true;              // false: no eps / code was supplied (VQ: draw the code on the device)
     uint8_t* pool_arg = nullptr;       // stem max-pool argmax codes (maxpool_idx_kernel)
     bool grads_dirty = false;
+    hipEvent_t ev_phase1 = nullptr;    // recorded inside train_backward once the transformer.* gradients are final
     float* det_ws = nullptr;           // slices / partials of the fixed-order reductions of the backward pass
     int64_t det_ws_floats = 0;
     float* scale_slots = nullptr;      // [SCALE_SLOTS][2]: device-computed operand scales of the f16x3 backward GEMMs

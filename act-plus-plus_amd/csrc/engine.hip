@@ -516,6 +516,7 @@ int engine_destroy(actmi_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->train && ctx->train->ev_phase1) (void)hipEventDestroy(ctx->train->ev_phase1);
     delete ctx->train;
     delete ctx;
     return 0;

@@ -424,6 +424,7 @@ int train_create(actmi_ctx* ctx) {
     TA(T.scale_slots, 2 * SCALE_SLOTS);
     // deterministic reductions: slices of split weight-gradient contractions and per-block partials of the LayerNorm /
     // bias-gradient sums, all combined in a fixed order (no float atomics: gradients are bitwise repeatable)
+    if (hipEventCreateWithFlags(&T.ev_phase1, hipEventDisableTiming) != hipSuccess) { ctx->err = "hipEventCreate failed"; return ACTMI_E_LAUNCH; }
     T.det_ws_floats = (int64_t)48 << 20;
     TA(T.det_ws, T.det_ws_floats);
     if (hipMemset(T.scale_slots, 0, 2 * SCALE_SLOTS * 4) != hipSuccess) { ctx->err = "hipMemset failed"; return ACTMI_E_LAUNCH; }
@@ -826,6 +827,10 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
     for (int l = g.enc_layers - 1; l >= 0; --l)
         CHK(enc_bwd(ctx, ctx->enc[l], T.en[l], T.gB, T.gB, ctx->pos_tokens, B, N, nullptr, dpos2,
                     Drop{dp, T.drop_seed, (uint32_t)(100 + 8 * l)}, st));
+    // every gradient of transformer.* (decoder + main encoder: the head of the arena) is final here, while the backbone and
+    // CVAE-encoder backward are still to be enqueued: a data-parallel caller lets its collective stream wait for this event
+    // and reduces that range under the rest of the backward (actmi_wait_grad_phase)
+    if (T.ev_phase1) HIPCHK(hipEventRecord(T.ev_phase1, st));
     float* dX = T.gB;                       // grad wrt the token matrix [B][N][D]
     // token 1: proprio = W_s qpos + b_s
     CHK(launch_small_linear_wgrad(dX + D, (int64_t)N * D, T.qpos, S, GP("input_proj_robot_state.weight"), B, D, S, st));

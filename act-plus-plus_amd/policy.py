@@ -36,9 +36,8 @@ class _Loss(torch.Tensor):
     def backward(self, *a, **k):      # noqa: D401
         import torch.distributed as dist
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        self._policy.model.backward(1.0 / world)       # data parallel: mean over the global batch
-        if world > 1:
-            self._policy.model.allreduce_grads()
+        # data parallel: mean over the global batch; the all-reduce of the transformer gradients runs under the backbone backward
+        self._policy.model.backward_allreduce(1.0 / world)
 
 
 class _AdamW:

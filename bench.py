@@ -441,9 +441,7 @@ def train_rig(cfg, B, dev, seed, world):
     def step(i):
         eng.zero_grad()
         out = eng.forward_train(t["qpos"], t["image_u8"], t["actions"], t["is_pad"], eps=t["eps"])
-        eng.backward(1.0 / world)
-        if world > 1:
-            eng.allreduce_grads()          # data-parallel training: bucketed gradient all-reduce over RCCL / xGMI
+        eng.backward_allreduce(1.0 / world)   # data parallel: bucketed all-reduce over RCCL, transformer range under the backbone backward
         eng.adamw_step(1e-5, 1e-5, 1e-4, step=i + 1)
         return out
     return eng, step

@@ -242,6 +242,14 @@ int actmi_grad_ptr(actmi_handle h, const char* key, void** dev_ptr, int64_t* num
 /* the whole gradient arena (same layout as the parameter arena) for bucketed data-parallel all-reduce over RCCL */
 int actmi_grad_arena(actmi_handle h, void** dev_ptr, int64_t* nfloats);
 
+/* Data-parallel overlap: actmi_backward records an event once the gradients of phase 1 -- every transformer.*
+ * parameter, the contiguous head [offset, offset + count) of the gradient arena reported by actmi_grad_phase_range -- are
+ * final, before the backbone / CVAE-encoder backward is enqueued.  actmi_wait_grad_phase makes `stream` (the stream the
+ * caller issues its RCCL collective from) wait for that event, so the reduction of that range runs under the rest of the
+ * backward; phase 2 is the remainder of the arena, final when the stream actmi_backward ran on has drained. */
+int actmi_grad_phase_range(actmi_handle h, int phase, int64_t* offset, int64_t* count);
+int actmi_wait_grad_phase(actmi_handle h, int phase, void* stream);
+
 /* ---- temporal ensembling over E episodes (imitate_episodes.py:338-339, 402-411) ------------------- */
 /* ring [E][Q][Q][A] f32 zero-initialised, tcount [E] i32 zero-initialised, chunk [E][Q][A] f32;
  * out [E][A] f64 (the reference's raw_action is float64), populated [E][Q] u8 or NULL (oldest row first). */

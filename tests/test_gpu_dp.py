@@ -37,6 +37,17 @@ def _rank(rank, world, port, outdir):
     eng.backward(1.0 / world)
     eng.allreduce_grads(bucket_mb=1)
     grads = {"g:" + k: eng.grad(k).cpu().numpy() for k in KEYS}
+    # the overlapped form (collective of the transformer range issued from a side stream that waits for the library's
+    # phase-1 event, the rest after the backward) must give the same averaged gradients
+    whole = eng.grad_arena().clone()
+    eng.zero_grad()
+    eng.forward_train(t["qpos"], t["image_u8"], t["actions"], t["is_pad"], eps=t["eps"])
+    eng.backward_allreduce(1.0 / world, bucket_mb=1)
+    torch.cuda.synchronize()
+    lo, n = eng.grad_phase_range(1)
+    lo2, n2 = eng.grad_phase_range(2)
+    assert lo == 0 and lo2 == n and n > 0 and n2 > 0 and n + n2 == whole.numel()
+    assert torch.equal(eng.grad_arena(), whole), "overlapped all-reduce differs from the plain one"
     eng.adamw_step(1e-3, 1e-4, 1e-4, step=1)
     if rank == 0:
         sd = eng.state_dict()
