@@ -224,6 +224,19 @@ def conv3x3_c64(x, w_ohwi, scale=None, bias=None, res=None, relu=False, w_scale=
     return out
 
 
+def conv3x3_direct(x, w_ohwi, scale, bias, res=None, relu=False, w_scale=256.0):
+    """direct 3x3 / stride 1 / pad 1 convolution, Cin and Cout multiples of 64 (f16x3): x [G,B,H,W,Cin], w_ohwi [G,Cout,3,3,Cin]."""
+    lib = L.load()
+    G, B, H, W, Cin = x.shape
+    Cout = w_ohwi.shape[1]
+    w16 = split16(w_ohwi, w_scale)
+    out = torch.empty((G, B, H, W, Cout), dtype=torch.float32, device=x.device)
+    L.check(lib.actmi_op_conv3x3_direct(_p(x.contiguous()), _p(w16), float(w_scale), _p(scale.contiguous()), _p(bias.contiguous()),
+                                        _p(res.contiguous() if res is not None else None), _p(out), G, B, H, W, Cin, Cout,
+                                        1 if relu else 0, L.current_stream_ptr()), None, "op_conv3x3_direct")
+    return out
+
+
 def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False, split=True, drop_p=0.0, drop_seed=0, prec=None,
               causal=False):
     """q [B,Nq,D] (or [Nq,D] when q_shared), k/v [B,Nk,D] (views with row stride allowed); returns [B,Nq,D]."""

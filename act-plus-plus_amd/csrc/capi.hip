@@ -288,6 +288,15 @@ int actmi_op_conv3x3_c64(const float* x, const float* w16, float w_scale, const 
     return launch_conv3x3_c64(a, S(stream), &g_op_error);
 }
 
+int actmi_op_conv3x3_direct(const float* x, const float* w16, float w_scale, const float* scale, const float* bias,
+                            const float* res, float* out, int G, int B, int H, int W, int Cin, int Cout, int relu, void* stream) {
+    g_op_error.clear();
+    Conv3gArgs a;
+    a.x = x; a.w16 = w16; a.scale = scale; a.bias = bias; a.res = res; a.out = out;
+    a.G = G; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu; a.w_scale = w_scale;
+    return launch_conv3x3_direct(a, S(stream), &g_op_error);
+}
+
 const char* actmi_op_last_error(void) { return g_op_error.c_str(); }
 
 int actmi_set_gemm_prec(actmi_handle h, int prec) {

@@ -79,6 +79,19 @@ struct Conv3Args {
 };
 int launch_conv3x3_c64(const Conv3Args& a, hipStream_t st, std::string* err);
 
+// ---- direct 3x3 / stride 1 / pad 1 convolution, Cin and Cout multiples of 64, f16x3 (conv3g.hip) ----------
+struct Conv3gArgs {
+    const float* x;       // camera-major NHWC [G][B][H][W][Cin]
+    const float* w16;     // fp16-split image (actmi_op_split16) of the weights [G][Cout][(r,s,c) = 9*Cin], built with w_scale
+    const float* scale;   // [G][Cout] folded FrozenBN
+    const float* bias;    // [G][Cout]
+    const float* res;     // optional residual, same shape as out
+    float* out;           // [G][B][H][W][Cout]
+    int G, B, H, W, Cin, Cout, relu;
+    float w_scale;
+};
+int launch_conv3x3_direct(const Conv3gArgs& a, hipStream_t st, std::string* err);
+
 // ---- 3x3/s2/p1 max pool NHWC (pool.hip) -----------------------------------------------------
 int launch_maxpool(const float* in, float* out, int nimg, int H, int W, int C, int Ho, int Wo, hipStream_t st);
 // horizontal half of the 3x3/s2/p1 pool on a vertically pooled map: out[h][pw] = max(in[h][2pw-1 .. 2pw+1])

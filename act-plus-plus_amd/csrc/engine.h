@@ -115,6 +115,8 @@ struct actmi_ctx {
     hipStream_t side_stream = nullptr; // downsample branch of the ResNet blocks (engine_backbone)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool ds_fork = true;
+    bool conv_direct = false;          // layer2-4 stride-1 3x3 convolutions on the direct kernel (conv3g.hip): measured slower, opt-in
+    int conv_direct_min_images = 8;    // below this many images (cameras x batch) its grid is too small: implicit GEMM + split-K
     int64_t ptotal = 0;
     bool finalized = false;
     // geometry

@@ -497,6 +497,13 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
         // contractions are being split (the side branch would share the slice workspace)
         const char* e = getenv("ACTMI_DS_FORK");
         ctx->ds_fork = !(e && e[0] == '0');
+        // layer2-4 stride-1 convolutions on the direct kernel of conv3g.hip: built, bit-checked and measured SLOWER than the
+        // implicit GEMM at 128-512 channels (B = 8: 187 / 203 / 251 us against 173 / 188 / 214 us per launch,
+        // profiles/r02_conv_direct_ab.json): re-staging the patch for every 64-channel chunk costs as much as the chunk's
+        // nine taps of MFMAs.  Off unless ACTMI_CONV_DIRECT=1.
+        const char* e3 = getenv("ACTMI_CONV_DIRECT");
+        ctx->conv_direct = e3 && e3[0] == '1';
+        if (const char* e4 = getenv("ACTMI_CONV_DIRECT_MIN_IMAGES")) ctx->conv_direct_min_images = atoi(e4);
         if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -658,6 +665,15 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
             c3.x = in; c3.w16 = cl.w16; c3.scale = cl.scale; c3.bias = cl.bias; c3.res = res; c3.out = out;
             c3.G = C; c3.B = B; c3.H = cl.H; c3.W = cl.W; c3.relu = relu; c3.w_scale = cl.w16_scale;
             return launch_conv3x3_c64(c3, cs, &ctx->err);
+        }
+        if (ctx->gemm_prec == ACTMI_PREC_F16X3 && ctx->conv_direct && cl.k == 3 && cl.stride == 1 && cl.pad == 1 &&
+            (cl.cin % 64) == 0 && (cl.cout % 64) == 0 && B * C >= ctx->conv_direct_min_images) {
+            // layer2-4 stride-1 convolutions: the same direct scheme per 64-channel chunk (conv3g.hip) -- a third fewer
+            // operand bytes per MFMA than the implicit GEMM at its 128x128 tile
+            Conv3gArgs cg;
+            cg.x = in; cg.w16 = cl.w16; cg.scale = cl.scale; cg.bias = cl.bias; cg.res = res; cg.out = out;
+            cg.G = C; cg.B = B; cg.H = cl.H; cg.W = cl.W; cg.Cin = cl.cin; cg.Cout = cl.cout; cg.relu = relu; cg.w_scale = cl.w16_scale;
+            return launch_conv3x3_direct(cg, cs, &ctx->err);
         }
         GemmArgs a;
         memset(&a, 0, sizeof(a));

@@ -293,6 +293,12 @@ int actmi_op_conv1(const void* image, int image_fmt, const float* w_oihw, const 
  * out = act(conv * scale + bias (+ res)) */
 int actmi_op_conv3x3_c64(const float* x, const float* w16, float w_scale, const float* scale, const float* bias,
                          const float* res, float* out, int G, int B, int H, int W, int relu, void* stream);
+/* the same scheme for Cin, Cout multiples of 64 (ResNet18 layer2-4 stride-1 convolutions): x [G][B][H][W][Cin], w16 =
+ * actmi_op_split16 image of [G][Cout][3][3][Cin], per 64-channel chunk an LDS-resident patch, wave blocks of 1x32 / 2x16 / 4x8
+ * output pixels chosen by the map width */
+int actmi_op_conv3x3_direct(const float* x, const float* w16, float w_scale, const float* scale, const float* bias,
+                            const float* res, float* out, int G, int B, int H, int W, int Cin, int Cout, int relu, void* stream);
+
 /* ---- DiffusionPolicy inference path (reference policy.py:20-241, imitate_episodes.py:100-118,420-426).
  * The non-GEMM pieces of what the reference delegates to robomimic (ResNet18Conv with BatchNorm -> GroupNorm, SpatialSoftmax,
  * ConditionalUnet1D) and diffusers (DDIMScheduler.step); restated from the published definitions, parity unpinned (neither
