@@ -1,13 +1,16 @@
+# bench line + rocprofv3 kernel stats + the two PMC traffic passes of one build (one gpurun call); outputs under gpurun_out/prof_r02
 set -e
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/prof_j
+O=$R/gpurun_out/prof_r02
+mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --steps 30 --warmup 5 > $R/gpurun_out/prof_j/bench_infer.json 2> $R/gpurun_out/prof_j/bench_infer.err
+python3 $R/bench.py --steps 30 --warmup 5 > $O/bench_infer.json 2> $O/bench_infer.err
 echo bench done >&2
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_j/kt -o kt -- python3 $R/bench.py --no-cpu-baseline --steps 30 --warmup 5 > $R/gpurun_out/prof_j/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --no-cpu-baseline --no-extras --sustained-s 0 --steps 30 --warmup 5 > $O/bench_under_rocprof.json 2>/dev/null
 echo kt done >&2
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_j/pf -o pf -- python3 $R/bench.py --no-cpu-baseline --no-graph --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pf -o pf -- python3 $R/bench.py --no-cpu-baseline --no-extras --sustained-s 0 --no-graph --steps 3 --warmup 1 > /dev/null 2>&1
 echo pf done >&2
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_j/pw -o pw -- python3 $R/bench.py --no-cpu-baseline --no-graph --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pw -o pw -- python3 $R/bench.py --no-cpu-baseline --no-extras --sustained-s 0 --no-graph --steps 3 --warmup 1 > /dev/null 2>&1
 echo pw done >&2
-find $R/gpurun_out/prof_j -name "*.csv" | head -20 >&2
+python3 $R/bench.py --shapes --no-extras --no-cpu-baseline --sustained-s 0 --steps 30 --warmup 5 > $O/bench_shapes.json 2>/dev/null
+find $O -name "*.csv" | head -20 >&2
