@@ -12,8 +12,8 @@ def short_name(n):
     n = n.replace("(anonymous namespace)::", "")
     n = re.sub(r"\(.*\)$", "", n).strip()
     n = n.replace(" ", "")
-    m = re.match(r"gemm_f32_kernel<(\d+),(\d+),(\d+),(\d+),(\d+),(\d+),(\d+),(\d+)>", n)
-    if m:       # <BM,BN,WM,WN,AMODE,BMODE,PREC,BSPLIT> -> the profiler's name
+    m = re.match(r"gemm_f32_kernel<(\d+),(\d+),(\d+),(\d+),(\d+),(\d+),(\d+),(\d+)(?:,\d+)?>", n)
+    if m:       # <BM,BN,WM,WN,AMODE,BMODE,PREC,BSPLIT[,UNMASKED]> -> the profiler's name
         g = m.groups()
         return "gemm_%s_kernel<%s>" % ("f16x3" if g[6] == "1" else "f32", ",".join(g[:6]))
     return n
