@@ -88,11 +88,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
     // XCD a contiguous run of tile ids so that neighbouring tiles (same A rows) share one L2.
     const int nwg = tiles_m * tiles_n;
     const int splitk = p.splitk > 1 ? p.splitk : 1;
-    int bid = blockIdx.x, zz = blockIdx.z;
-    if (splitk == 1) {
-        // the remap runs over the FLATTENED (group, tile) space: an XCD then works through one group's tiles at a time
-        // (for the per-camera convolutions: one camera's weights per XCD instead of a slice of every camera at once --
-        // layer3/4 fetched 10-12x their operand bytes through the fabric before this)
+    int bid, zz;
+    {
+        // the remap runs over the FLATTENED (group, split, tile) space: an XCD then works through one group's (and one
+        // K slice's) tiles at a time (for the per-camera convolutions: one camera's weights per XCD instead of a slice of
+        // every camera at once -- layer3/4 fetched 10-12x their operand bytes through the fabric before this; a split-K
+        // launch whose planes were dealt over all 8 XCDs fetched every K slice's operands into every L2: 670 MB
+        // instead of 210 MB for the layer4 convolutions at splitk = 4, PMC round 2)
         const int total = nwg * (int)gridDim.z;
         const int lin = blockIdx.z * gridDim.x + blockIdx.x;
         const int xcd = lin & 7, q = total >> 3, r = total & 7;
@@ -100,10 +102,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
         const int flat = base + (lin >> 3);
         zz = flat / nwg;
         bid = flat - zz * nwg;
-    } else {
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        bid = base + (bid >> 3);
     }
     // grouped rasterisation: walk the tile grid in bands of GROUP_M tile rows, column by column, so that the ~64 tiles
     // an XCD runs concurrently form a compact patch (8 A panels x 8 B panels) and re-use each other's operand panels
