@@ -43,7 +43,7 @@ class GemmDesc(C.Structure):
         ("gA2", C.c_int64), ("gB2", C.c_int64), ("gC2", C.c_int64), ("gRes2", C.c_int64),
         ("gMask", C.c_int64), ("gC2out", C.c_int64),
         ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("stamps", C.c_void_p), ("prec", C.c_int32), ("b_split", C.c_int32), ("b_scale", C.c_float), ("a_scale", C.c_float), ("a_scale_dev", C.c_void_p), ("b_scale_dev", C.c_void_p),
-        ("split_stride", C.c_int64),
+        ("split_stride", C.c_int64), ("amax_out", C.c_void_p),
     ]
 
 

@@ -248,6 +248,28 @@ __global__ void attn_probs_kernel(float* __restrict__ S, const float* __restrict
     S[idx] = v;
 }
 
+// the same over 16-byte pieces of the rows (ldp % 4 == 0), 32-bit index arithmetic, bounded grid
+__global__ __launch_bounds__(256) void attn_probs_vec_kernel(f32x4* __restrict__ S, const float* __restrict__ lse,
+                                                             const uint8_t* __restrict__ kpm, int64_t kpm_bs, unsigned H, unsigned Nq,
+                                                             int Nk, unsigned ldp4, unsigned total4) {
+    const unsigned step = gridDim.x * 256u;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += step) {
+        const unsigned gq = i / ldp4;
+        const int k0 = (int)(i - gq * ldp4) * 4;
+        const float l = lse[gq];
+        const f32x4 s = S[i];
+        const uint8_t* km = kpm ? kpm + (int64_t)(gq / Nq / H) * kpm_bs + k0 : nullptr;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool live = k0 + e < Nk && !(km && km[e] != 0);
+            v[e] = live ? expf(s[e] - l) : 0.f;
+        }
+        S[i] = v;
+        if (i + step < i) break;
+    }
+}
+
 // dS = P * (dP - delta[g][q]) * scale, in place of dP
 __global__ void attn_ds_kernel(const float* __restrict__ P, float* __restrict__ dP, const float* __restrict__ delta,
                                float scale, int Nk, int ldp, int64_t total) {
@@ -256,6 +278,32 @@ __global__ void attn_ds_kernel(const float* __restrict__ P, float* __restrict__ 
     const int k = (int)(idx % ldp);
     const int64_t gq = idx / ldp;
     dP[idx] = (k < Nk) ? P[idx] * (dP[idx] - delta[gq]) * scale : 0.f;
+}
+
+// the same over 16-byte pieces; amax_bits (optional) collects the bits of max |dS| (operand scale of the dQ / dK products)
+__global__ __launch_bounds__(256) void attn_ds_vec_kernel(const f32x4* __restrict__ P, f32x4* __restrict__ dP,
+                                                          const float* __restrict__ delta, float scale, int Nk, unsigned ldp4,
+                                                          unsigned total4, unsigned* __restrict__ amax_bits) {
+    const unsigned step = gridDim.x * 256u;
+    unsigned am = 0;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += step) {
+        const unsigned gq = i / ldp4;
+        const int k0 = (int)(i - gq * ldp4) * 4;
+        const float dl = delta[gq];
+        const f32x4 pr = P[i], d = dP[i];
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = (k0 + e < Nk) ? pr[e] * (d[e] - dl) * scale : 0.f;
+            am = max(am, __float_as_uint(v[e]) & 0x7fffffffu);
+        }
+        dP[i] = v;
+        if (i + step < i) break;
+    }
+    if (amax_bits) {
+        for (int o = 32; o > 0; o >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, o, 64));
+        if ((threadIdx.x & 63) == 0 && am) amax_commit(amax_bits, am);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- losses
@@ -384,18 +432,43 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ gp, float* __restr
     g_oihw[idx] += gp[o * kpad + (r * KW + s) * ipack + c];      // accumulate like autograd
 }
 
-// y = x * (mask > 0) * scale[c]; also y_plain = x * (mask > 0)   (ReLU + FrozenBN backward on NHWC maps)
-__global__ void relu_bn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ add, const float* __restrict__ mask,
-                                   const float* __restrict__ scale, float* __restrict__ y_plain, float* __restrict__ y_scaled,
-                                   int C, int64_t per_group, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c = (int)(idx % C);
-    const int64_t g = idx / per_group;
-    float v = x[idx] + (add ? add[idx] : 0.f);
-    if (mask && !(mask[idx] > 0.f)) v = 0.f;
-    if (y_plain) y_plain[idx] = v;
-    if (y_scaled) y_scaled[idx] = v * scale[g * C + c];
+// y = x * (mask > 0) * scale[c]; also y_plain = x * (mask > 0)   (ReLU + FrozenBN backward on NHWC maps).
+// Four consecutive channels per thread (C % 4 == 0); amax_bits (optional) collects the bits of max |y_scaled| for the
+// power-of-two operand scale of the GEMMs that read y_scaled next (train.hip: dyn_scale) -- integer atomicMax, so the
+// result does not depend on the order of arrival.
+__global__ __launch_bounds__(256) void relu_bn_bwd_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ add,
+                                                          const f32x4* __restrict__ mask, const float* __restrict__ scale,
+                                                          f32x4* __restrict__ y_plain, f32x4* __restrict__ y_scaled, unsigned C4,
+                                                          unsigned per_group4, unsigned* __restrict__ amax_bits) {
+    // blockIdx.y = group (camera: its own FrozenBN scale); a bounded grid walks the group's map, so the amax costs one
+    // atomic per wave of a few thousand waves (one per wave of a one-element-per-thread grid: millions on one address)
+    const int64_t gbase = (int64_t)blockIdx.y * per_group4;
+    const float* sc_g = scale ? scale + (int64_t)blockIdx.y * C4 * 4 : nullptr;
+    const unsigned step = gridDim.x * 256u;
+    unsigned am = 0;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < per_group4; i += step) {
+        const int64_t idx = gbase + i;
+        f32x4 v = x[idx];
+        if (add) v += add[idx];
+        if (mask) {
+            const f32x4 mk = mask[idx];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+        }
+        if (y_plain) y_plain[idx] = v;
+        if (y_scaled) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(sc_g + (i % C4) * 4);
+            v = v * sc;
+            y_scaled[idx] = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) am = max(am, __float_as_uint(v[e]) & 0x7fffffffu);
+        }
+        if (i + step < i) break;                               // 32-bit wrap
+    }
+    if (amax_bits) {
+        for (int o = 32; o > 0; o >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, o, 64));
+        if ((threadIdx.x & 63) == 0 && am) amax_commit(amax_bits, am);
+    }
 }
 
 // dz[i] = keep(seed, i) ? dy[i] / (1-p) : 0   (backward of an epilogue dropout; i = element index of the forward output)
@@ -573,19 +646,35 @@ int launch_attn_probs(float* S, const float* lse, const uint8_t* kpm, int64_t kp
     const int64_t total = (int64_t)G * Nq * ldp;
     if (total <= 0) return 0;
     prof_begin("attn_probs_kernel", 0.0, 8.0 * total, st);
-    hipLaunchKernelGGL(attn_probs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, S, lse, kpm, kpm_bs, H, Nq,
-                       Nk, ldp, total);
+    if ((ldp & 3) == 0 && ((uintptr_t)S & 15) == 0 && total / 4 < ((int64_t)1 << 32)) {
+        const unsigned t4 = (unsigned)(total / 4);
+        unsigned blocks = (t4 + 256u * 4u - 1) / (256u * 4u);
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(attn_probs_vec_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<f32x4*>(S), lse, kpm, kpm_bs,
+                           (unsigned)H, (unsigned)Nq, Nk, (unsigned)(ldp / 4), t4);
+    } else
+        hipLaunchKernelGGL(attn_probs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, S, lse, kpm, kpm_bs, H, Nq,
+                           Nk, ldp, total);
     prof_end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 int launch_attn_ds(const float* P, float* dP, const float* delta, float scale, int G, int Nq, int Nk, int ldp,
-                   hipStream_t st) {
+                   hipStream_t st, unsigned* amax_bits) {
     const int64_t total = (int64_t)G * Nq * ldp;
     if (total <= 0) return 0;
+    const bool vec = (ldp & 3) == 0 && ((uintptr_t)P & 15) == 0 && ((uintptr_t)dP & 15) == 0 && total / 4 < ((int64_t)1 << 32);
+    if (amax_bits && !vec) return -2;                       // the caller registered a producer-side amax: only this form has it
     prof_begin("attn_ds_kernel", 0.0, 12.0 * total, st);
-    hipLaunchKernelGGL(attn_ds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, dP, delta, scale, Nk, ldp,
-                       total);
+    if (vec) {
+        const unsigned t4 = (unsigned)(total / 4);
+        unsigned blocks = (t4 + 256u * 4u - 1) / (256u * 4u);
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(attn_ds_vec_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(P),
+                           reinterpret_cast<f32x4*>(dP), delta, scale, Nk, (unsigned)(ldp / 4), t4, amax_bits);
+    } else
+        hipLaunchKernelGGL(attn_ds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, dP, delta, scale, Nk, ldp,
+                           total);
     prof_end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -701,11 +790,21 @@ int launch_unpack_wgrad(const float* gp, float* g_oihw, int O, int I, int KH, in
 }
 
 int launch_relu_bn_bwd(const float* x, const float* add, const float* mask, const float* scale, float* y_plain,
-                       float* y_scaled, int G, int64_t per_group, int C, hipStream_t st) {
+                       float* y_scaled, int G, int64_t per_group, int C, hipStream_t st, unsigned* amax_bits) {
     const int64_t total = (int64_t)G * per_group;
+    // NHWC maps with C % 4 == 0 (base_width multiples of 4); one group's map below 2^32 16-byte pieces
+    if ((C & 3) || (per_group & 3) || per_group / 4 >= ((int64_t)1 << 32) || G > 65535) return -2;
+    if (total == 0) return 0;
+    const int64_t pg4 = per_group / 4;
+    int64_t bx = (pg4 + 256 * 8 - 1) / (256 * 8);              // ~8 pieces per thread
+    const int64_t cap = 4096 / G > 0 ? 4096 / G : 1;
+    if (bx > cap) bx = cap;
+    if (bx < 1) bx = 1;
     prof_begin("relu_bn_bwd_kernel", 0.0, 16.0 * total, st);
-    hipLaunchKernelGGL(relu_bn_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, add, mask, scale,
-                       y_plain, y_scaled, C, per_group, total);
+    hipLaunchKernelGGL(relu_bn_bwd_kernel, dim3((unsigned)bx, (unsigned)G), dim3(256), 0, st,
+                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<const f32x4*>(add), reinterpret_cast<const f32x4*>(mask),
+                       scale, reinterpret_cast<f32x4*>(y_plain), reinterpret_cast<f32x4*>(y_scaled), (unsigned)(C / 4), (unsigned)pg4,
+                       amax_bits);
     prof_end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -7,6 +7,16 @@
 #include "actmi.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef __HIPCC__
+// Running maximum of |x| bits shared by a whole launch (the operand-scale slots of the backward pass): `v` is the calling
+// wave's maximum, already reduced over its lanes; call from ONE lane.  Device-scope atomics resolve at the memory side and
+// serialise on the address (~6 ns each: 150k waves cost a millisecond), so a wave first looks at the current value with a
+// device-scope load and only issues the atomic when it would raise it -- after the first few waves almost none do.
+__device__ __forceinline__ void amax_commit(unsigned* bits, unsigned v) {
+    if (v > __hip_atomic_load(bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(bits, v);
+}
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define ACTMI_WAVE 64
@@ -141,7 +151,7 @@ int launch_attn_delta(const float* dO, const float* O, float* delta, int B, int 
 int launch_attn_probs(float* S, const float* lse, const uint8_t* kpm, int64_t kpm_bs, int G, int H, int Nq, int Nk, int ldp,
                       hipStream_t st);
 int launch_attn_ds(const float* P, float* dP, const float* delta, float scale, int G, int Nq, int Nk, int ldp,
-                   hipStream_t st);
+                   hipStream_t st, unsigned* amax_bits = nullptr);
 // losses: [3] results followed by >= 513 floats of scratch (block partials of the l1 sum: fixed-order total)
 int launch_losses(const float* a_hat, const float* actions, const uint8_t* is_pad, const float* latent_info, float* losses,
                   int B, int Q, int A, int L, float kl_weight, hipStream_t st);
@@ -160,7 +170,7 @@ int launch_adamw(float* p, const float* g, float* m, float* v, const uint8_t* gr
 int launch_repack_dgrad_w(const float* wf, float* wd, int G, int O, int I, int KK, hipStream_t st);
 int launch_unpack_wgrad(const float* gp, float* g_oihw, int O, int I, int KH, int KW, int kpad, int ipack, hipStream_t st);
 int launch_relu_bn_bwd(const float* x, const float* add, const float* mask, const float* scale, float* y_plain,
-                       float* y_scaled, int G, int64_t per_group, int C, hipStream_t st);
+                       float* y_scaled, int G, int64_t per_group, int C, hipStream_t st, unsigned* amax_bits = nullptr);
 int launch_normalize_pad(const void* image, int fmt, const float* lut, float* out, int B, int C, int H, int W,
                          hipStream_t st);
 int launch_gather_rows(const float* src, const int* map, float* dst, int M, int D, hipStream_t st);
@@ -170,6 +180,7 @@ int launch_cvae_maps(int* map, uint8_t* kpm, const uint8_t* is_pad, int B, int Q
 int launch_axpy(float* dst, const float* src, int64_t n, hipStream_t st);
 int launch_scale(float* x, int64_t n, float s, hipStream_t st);
 int launch_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, hipStream_t st);
+int launch_pow2_from_bits(float* out, hipStream_t st);      // the scale from bits a producing kernel left in out[1]
 int launch_split16(const float* src, float* dst, int64_t nfloats, float scale, hipStream_t st, uint32_t* flag = nullptr);
 // range guard of the f16x3 weight images (misc.hip): per-segment max |x| (as float bits), the parameter arena split with one
 // power-of-two scale per parameter, and the finite check of an output

@@ -77,7 +77,8 @@ struct TrainState {
     float* scale_slots = nullptr;      // [SCALE_SLOTS][2]: device-computed operand scales of the f16x3 backward GEMMs
     int scale_next = 0;
     const float* amax_key_ptr = nullptr; int64_t amax_key_ld = 0; int amax_key_m = 0, amax_key_n = 0;   // one-shot reuse
-    const float* amax_key_slot = nullptr;          // the gradient arena holds gradients of an earlier backward (no zero_grad since)
+    const float* amax_key_slot = nullptr;
+    const float* amax_pre_ptr = nullptr; float* amax_pre_slot = nullptr;   // a producer kernel left this tensor's amax bits          // the gradient arena holds gradients of an earlier backward (no zero_grad since)
     float *qkd = nullptr, *sO = nullptr, *lse_s = nullptr, *saB = nullptr, *T1B = nullptr, *dqB = nullptr, *gT1 = nullptr,
           *dsaB = nullptr, *dqkB = nullptr, *dvB = nullptr, *dqk_d = nullptr, *tmpQD = nullptr;
     // backward scratch

@@ -703,8 +703,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
     const bool simple = !has_map && (splitk <= 1 || p.split_stride != 0) && !C2 && !(p.drop_p > 0.f) && p.res_mod == 0 &&
                         (!has_mask || (int64_t)p.M * ldmask < (int64_t)1 << 31) &&
                         (int64_t)p.M * p.ldc < (int64_t)1 << 31 && (!has_res || (int64_t)p.M * p.ldres < (int64_t)1 << 31);
+    unsigned amx = 0;                  // bits of max |stored value| (p.amax_out)
+    auto amax_flush = [&]() {
+        if (!p.amax_out) return;
+        for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
+        if (lane == 0 && amx) amax_commit(p.amax_out, amx);
+    };
     if (simple) {
         const bool relu = p.relu == 1, gelu = p.relu == 2;
+
         // Vector form: the wave's accumulator tile goes through the (now idle) LDS stage one 32-row band at a time and
         // leaves as 16-byte stores, a row segment of WN floats per WN/4 lanes -- 4x fewer store instructions, each
         // covering whole 128-byte lines.  (The scalar form below writes 4 bytes per lane; its store burst was measured
@@ -754,9 +761,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                             for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
                         }
                         *reinterpret_cast<f32x4*>(C + (uint32_t)(m * (int)p.ldc + ncol)) = v;
+                        if (p.amax_out) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) amx = max(amx, __float_as_uint(v[e]) & 0x7fffffffu);
+                        }
                     }
                 }
             }
+            amax_flush();
             if (stamp && threadIdx.x == 0) stamp[3] = __builtin_amdgcn_s_memtime();
             return;
         }
@@ -786,11 +798,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                     if (has_mask && nok && m < p.M) { if (!(mask[(uint32_t)(m * (int)ldmask + n)] > 0.f)) v = 0.f; }
                     v = relu ? fmaxf(v, 0.f) : v;
                     if (gelu) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-                    if (nok && m < p.M) C[(uint32_t)(m * (int)p.ldc + n)] = v;
+                    if (nok && m < p.M) {
+                        C[(uint32_t)(m * (int)p.ldc + n)] = v;
+                        if (p.amax_out) amx = max(amx, __float_as_uint(v) & 0x7fffffffu);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        amax_flush();
         if (stamp && threadIdx.x == 0) stamp[3] = __builtin_amdgcn_s_memtime();
         return;
     }
@@ -839,12 +855,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (splitk > 1 && p.split_stride == 0) atomicAdd(&C[o], v);
                     else C[o] = v;
+                    if (p.amax_out) amx = max(amx, __float_as_uint(v) & 0x7fffffffu);
                     if (C2) C2[o] = v * sc2;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the next tile's loads from being hoisted (register pressure)
         }
     }
+    amax_flush();
     if (stamp && threadIdx.x == 0) stamp[3] = __builtin_amdgcn_s_memtime();
 }
 

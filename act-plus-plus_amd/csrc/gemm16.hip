@@ -19,8 +19,10 @@
 //   * the two waves that share a SIMD (wave w and w+4) run half a K tile apart ("ping-pong"): while one issues its MFMAs
 //     (and its share of the DMA for a later step) the other reads its fragments; two barriers per K tile.
 //
-// Tile: BM x 128 outputs, BM = 128 or 256; wave (g, n) = (w >> 2, w & 3) owns rows [g*BM/2, (g+1)*BM/2) x columns
-// [32n, 32n+32): BM/64 MFMA tiles of 32x32, 3 * 2 * BM/64 MFMAs per K tile of 32.
+// Tile: BM x BN outputs, (BM, BN) = (128, 128), (256, 128) or (256, 256); wave (g, n) = (w >> 2, w & 3) owns rows
+// [g*BM/2, (g+1)*BM/2) x columns [n*BN/4, (n+1)*BN/4): BM/64 x BN/128 MFMA tiles of 32x32, 3 * 2 * that many MFMAs per K tile
+// of 32.  The 256 x 256 tile has room for two ring stages only (2 x 64 KB + 32 KB scratch): loads run ONE step ahead, a step
+// being 48 MFMAs per wave.
 // A forms: plain rows (nn.Linear, MHA projections, FFN, 1x1 input_proj: transformer.py:196-224, detr_vae.py:184) and the NHWC
 // implicit im2col of the 3x3 / 1x1 ResNet convolutions with Cin % 32 == 0 (a K tile lies inside one filter tap; padding
 // taps read a zero line).  Epilogue: acc * alpha * scale[n] + bias[n] (+ residual: s16 tensor or an f32 table indexed by
@@ -41,24 +43,29 @@ namespace {
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BN = 128;
 constexpr int ROWB = 128;                    // bytes of one operand row per K tile (32 fp32-k)
 constexpr int NTHR = 512;
 constexpr int SCR_ROWS = 32;                 // epilogue scratch: one 32-row chunk of the tile at a time
-constexpr int SCR_BYTES = SCR_ROWS * BN * 4; // 16 KB: with the 3 x 48 KB ring of the 256-row tile exactly the CU's 160 KB
 constexpr int NUM_CU = 256;
 #ifndef ACTMI_G16_GL
 #define ACTMI_G16_GL 3
 #endif
 
-template <int BM> struct Cfg {
-    static constexpr int NS = (BM == 256) ? 3 : 4;
+template <int BM, int BN> struct Cfg {
+    // 128 x 128: 4 x 32 KB; 256 x 128: 3 x 48 KB; 256 x 256: 2 x 64 KB -- with the epilogue scratch (one 32-row chunk of the
+    // tile: 16 / 32 KB) the two large tiles take exactly the CU's 160 KB
+    static constexpr int NS = (BN == 256) ? 2 : (BM == 256) ? 3 : 4;
     static constexpr int STAGE = (BM + BN) * ROWB;
+    static constexpr int SCR_BYTES = SCR_ROWS * BN * 4;
     static constexpr int GA = BM / 64;           // A-side DMA instructions per wave and K tile
     static constexpr int GB = BN / 64;           // B-side
     static constexpr int G = GA + GB;
     static constexpr int TM = BM / 64;           // 32x32 MFMA tiles per wave (rows)
+    static constexpr int TN = BN / 128;          // (columns)
     static constexpr int NCH = BM / SCR_ROWS;    // epilogue chunks
+    static constexpr int TPR = BN / 8;           // epilogue: threads per output row (8 floats each)
+    static constexpr int RPP = NTHR / TPR;       // rows per pass
+    static constexpr int NPASS = SCR_ROWS / RPP; // passes per chunk
     static constexpr int SMEM = NS * STAGE + SCR_BYTES;
 };
 
@@ -91,11 +98,11 @@ __device__ __forceinline__ void dma16(const void* src, unsigned char* lds_dst) {
 struct TileId { int g, split, m0, n0; };
 template <int V> using IC = std::integral_constant<int, V>;
 
-template <int BM, int CONV>
+template <int BM, int BN, int CONV>
 __global__ __launch_bounds__(NTHR) void gemm16_kernel(Gemm16Args p, int tiles_m, int tiles_n, int total_tiles) {
-    using C = Cfg<BM>;
-    constexpr int NS = C::NS, G = C::G, TM = C::TM;
-    constexpr int SEPI = 2 * C::NCH;                      // store instructions per wave in the epilogue of a full tile
+    using C = Cfg<BM, BN>;
+    constexpr int NS = C::NS, G = C::G, TM = C::TM, TN = C::TN, NPASS = C::NPASS;
+    constexpr int SEPI = 2 * NPASS * C::NCH;                   // store instructions per wave in the epilogue of a full tile
     static_assert((NS - 2) * G + SEPI < 64, "vmcnt literal out of range");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(NTHR) void gemm16_kernel(Gemm16Args p, int tiles_m,
             for (int q = 0; q < 2; ++q) co[s][q] = ((2 * (2 * s + lh) + q) ^ sw) << 4;
     }
     const int a_row_off = (grp * (BM / 2) + li) * ROWB;
-    const int b_row_off = BM * ROWB + (wn * 32 + li) * ROWB;
+    const int b_row_off = BM * ROWB + (wn * (32 * TN) + li) * ROWB;
 
     // ---- the stream.  Step c = 0 .. nsteps-1 is (tile c / nk, K tile c % nk); its operands live in ring stage c % NS.
     //      Step c + NS-1 is issued by every wave during its step c: the first GL of its G DMA instructions at the head of
@@ -265,8 +272,8 @@ __global__ __launch_bounds__(NTHR) void gemm16_kernel(Gemm16Args p, int tiles_m,
     uint64_t* stamp = (p.stamps && wg == 0 && t == 0) ? p.stamps : nullptr;
     if (stamp) { stamp[1] = __builtin_amdgcn_s_memtime(); stamp[62] = __builtin_amdgcn_s_memrealtime(); }
 
-    f32x16 acc[TM];
-    u32x4 fa[2][TM][2], fb[2][2];
+    f32x16 acc[TM][TN];
+    u32x4 fa[2 / (TN > 1 ? 2 : 1)][TM][2], fb[2 / (TN > 1 ? 2 : 1)][TN][2];
     // steps whose wait must look past the SEPI stores of a full tile's epilogue: the DMA of the first NS-2 steps waited
     // for after an epilogue was issued BEFORE those stores (vmcnt retires in issue order)
     int store_debt = 0;
@@ -285,75 +292,99 @@ __global__ __launch_bounds__(NTHR) void gemm16_kernel(Gemm16Args p, int tiles_m,
             else vmcnt_wait<0>();
         }
     };
+    // A step (one K tile of 32) runs as NH phase pairs L / C: NH = 1 reads both 16-deep halves' fragments in one L phase
+    // (96 fragment registers at most with the 128-column tiles); the 256 x 256 tile (128 accumulator registers per wave,
+    // 256 registers per wave at 2 waves per SIMD) takes the halves one at a time (NH = 2, 48 fragment registers live).
+    constexpr int NH = (TN > 1) ? 2 : 1, KS = 2 / NH;
+    // DMA instructions of the step issued in half h: all of them in half 0 by default (a full step of lead even with the
+    // 2-stage ring); GL of a half's share at the head of its L phase, the rest woven into its C phase
+#ifndef ACTMI_G16_H0
+#define ACTMI_G16_H0 (C::G)
+#endif
+    constexpr int GH0 = (NH == 1) ? G : (ACTMI_G16_H0 < G ? ACTMI_G16_H0 : G);
     auto step = [&](int c, auto steady) {
         constexpr bool STEADY = decltype(steady)::value;
-        // ---------------- L(c): this wave's share of the DMA for step c + NS - 1, then the fragments of step c.
-        //                  Runs at priority 1, raised BEFORE the barrier that opens it: the partner wave on this SIMD is
-        //                  then issuing MFMAs back to back, and a wave released from the barrier at equal priority did not
-        //                  get to issue anything for the length of that burst (in-kernel stamps: 384 / 550 cycles)
-        constexpr int GL = ACTMI_G16_GL < C::G ? ACTMI_G16_GL : C::G;      // DMA instructions issued in the L phase
-        if (STEADY) {
-            if (i_kt == 0) setup(tile_of(i_tile));           // the issue cursor enters a new tile (once per tile)
-            issue_part(i_kt, i_step % NS, IC<0>{}, IC<GL>{});
-        }
-        {
-            const unsigned st = lds0 + (unsigned)(c % NS) * C::STAGE;
+        const unsigned st = lds0 + (unsigned)(c % NS) * C::STAGE;
+        auto half = [&](auto hc) {
+            constexpr int H = decltype(hc)::value;
+            constexpr int J0 = (H == 0) ? 0 : GH0, J1 = (H == 0) ? GH0 : G;        // this half's DMA instructions
+            constexpr int GLH = (J1 - J0) < ACTMI_G16_GL ? (J1 - J0) : ACTMI_G16_GL;
+            constexpr bool LAST = (H == NH - 1);
+            // ---------------- L: this wave's share of the DMA for step c + NS - 1, then the fragments of this half.
+            //                  Runs at priority 1, raised BEFORE the barrier that opens it: the partner wave on this SIMD is
+            //                  then issuing MFMAs back to back, and a wave released from the barrier at equal priority did not
+            //                  get to issue anything for the length of that burst (in-kernel stamps: 384 / 550 cycles)
+            if (STEADY) {
+                if (H == 0 && i_kt == 0) setup(tile_of(i_tile));           // the issue cursor enters a new tile (once per tile)
+                issue_part(i_kt, i_step % NS, IC<J0>{}, IC<J0 + GLH>{});
+            }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < KS; ++s) {
+                const int sg = H * KS + s;                 // 16-deep half of the K tile
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const unsigned ab = st + a_row_off + co[s][q], bb = st + b_row_off + co[s][q];
-                    fb[s][q] = lds_read16<0>(bb);
+                    const unsigned ab = st + a_row_off + co[sg][q], bb = st + b_row_off + co[sg][q];
+                    fb[s][0][q] = lds_read16<0>(bb);
+                    if (TN > 1) fb[s][1 % TN][q] = lds_read16<32 * ROWB>(bb);
                     fa[s][0][q] = lds_read16<0>(ab);
                     if (TM > 1) fa[s][1 % TM][q] = lds_read16<32 * ROWB>(ab);
                     if (TM > 2) fa[s][2 % TM][q] = lds_read16<64 * ROWB>(ab);
                     if (TM > 3) fa[s][3 % TM][q] = lds_read16<96 * ROWB>(ab);
                 }
             }
-        }
-        if (grp == 1) wait_next_landed(steady, c);
-        lgkm_wait0();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---------------- C(c): the MFMAs of step c, back to back
-        __builtin_amdgcn_s_setprio(0);
-        if (STEADY) {
-            issue_part(i_kt, i_step % NS, IC<GL>{}, IC<C::G>{});
-            ++i_step;
-            if (++i_kt == nk) { i_kt = 0; ++i_tile; }
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const h16x8 yh = __builtin_bit_cast(h16x8, fb[s][0]), yl = __builtin_bit_cast(h16x8, fb[s][1]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const h16x8 xh = __builtin_bit_cast(h16x8, fa[s][i][0]), xl = __builtin_bit_cast(h16x8, fa[s][i][1]);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yh, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yl, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, acc[i], 0, 0, 0);
+            if (LAST && grp == 1) wait_next_landed(steady, c);
+            lgkm_wait0();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- C: the MFMAs of this half, back to back
+            __builtin_amdgcn_s_setprio(0);
+            if (STEADY) {
+                issue_part(i_kt, i_step % NS, IC<J0 + GLH>{}, IC<J1>{});
+                if (LAST) {
+                    ++i_step;
+                    if (++i_kt == nk) { i_kt = 0; ++i_tile; }
+                }
             }
-        }
-        if (STEADY && GL < C::G) {
-            constexpr int NC = C::G - GL, NMF = 6 * TM, PER = NMF / (NC + 1);
 #pragma unroll
-            for (int j = 0; j < NC; ++j) {
-                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);       // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);         // address arithmetic (VALU / SALU)
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // one LDS-DMA (VMEM read)
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const h16x8 yh = __builtin_bit_cast(h16x8, fb[s][j][0]), yl = __builtin_bit_cast(h16x8, fb[s][j][1]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const h16x8 xh = __builtin_bit_cast(h16x8, fa[s][i][0]), xl = __builtin_bit_cast(h16x8, fa[s][i][1]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, acc[i][j], 0, 0, 0);
+                    }
+                }
             }
-        }
-        __builtin_amdgcn_s_setprio(1);                       // for the L phase that follows the barrier below
-        if (grp == 0) wait_next_landed(steady, c);
-        if (store_debt > 0) --store_debt;
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+            if (STEADY && J1 - J0 - GLH > 0) {
+                constexpr int NC = J1 - J0 - GLH, NMF = 3 * KS * TM * TN, PER = NMF / (NC + 1);
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);       // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);         // address arithmetic (VALU / SALU)
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // one LDS-DMA (VMEM read)
+                }
+            }
+            __builtin_amdgcn_s_setprio(1);                       // for the L phase that follows the barrier below
+            if (LAST) {
+                if (grp == 0) wait_next_landed(steady, c);
+                if (store_debt > 0) --store_debt;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        half(IC<0>{});
+        if (NH > 1) half(IC<NH - 1>{});
     };
 
     // ---- epilogue of one finished tile (all 8 waves, aligned).  C layout of a 32x32 MFMA tile: col = lane & 31,
     //      row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).  The tile leaves in 32-row chunks through a 16 KB LDS scratch as
     //      full rows: 16 lanes x 32 bytes = one 512-byte row segment per row.
-    const int c8 = t & 15, r0 = t >> 4;
-    const unsigned scr_w = scr0 + (unsigned)((4 * lh) * BN + wn * 32 + li) * 4;       // + ((e&3) + 8(e>>2)) * BN * 4
+    const int c8 = t % C::TPR, r0 = t / C::TPR;
+    const unsigned scr_w = scr0 + (unsigned)((4 * lh) * BN + wn * (32 * TN) + li) * 4;       // + ((e&3) + 8(e>>2)) * BN * 4 + 128 j
     const unsigned scr_r = scr0 + (unsigned)(r0 * BN + c8 * 8) * 4;
     auto epilogue = [&](const TileId& ti, auto fullc) {
         constexpr bool FULL = decltype(fullc)::value;      // every row / column of the tile exists: store counts are literals
@@ -385,82 +416,98 @@ __global__ __launch_bounds__(NTHR) void gemm16_kernel(Gemm16Args p, int tiles_m,
         const float res_mul = (p.res_scale != 0.f ? p.res_scale : 1.f) * out_mul;
         const bool guard = p.c_fmt && p.flag != nullptr;
         float vmax = 0.f;
-        u32x4 rbuf[2][2];
-        auto res_ptr = [&](int ch) {
-            int m = ti.m0 + ch * SCR_ROWS + r0;
+        u32x4 rbuf[2][NPASS][2];
+        auto res_ptr = [&](int ch, int ps) {
+            int m = ti.m0 + ch * SCR_ROWS + ps * C::RPP + r0;
             m = m < p.M ? m : p.M - 1;
             const int mr = p.res_mod ? m % p.res_mod : m;
             return res + ((int64_t)mr * p.ldres + (nok ? n : 0)) * 4;
         };
-        if (res) { const unsigned char* rp = res_ptr(0); rbuf[0][0] = glb_read16(rp); rbuf[0][1] = glb_read16(rp + 16); }
+        auto res_load = [&](int ch) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const unsigned char* rp = res_ptr(ch, ps);
+                rbuf[ch & 1][ps][0] = glb_read16(rp); rbuf[ch & 1][ps][1] = glb_read16(rp + 16);
+            }
+        };
+        if (res) res_load(0);
 #pragma unroll
         for (int ch = 0; ch < C::NCH; ++ch) {
-            // the wave group that owns rows [32 ch, 32 ch + 32) writes its accumulator tile into the scratch
+            // the wave group that owns rows [32 ch, 32 ch + 32) writes its accumulator tiles into the scratch
             constexpr int CPG = C::NCH / 2;                     // chunks per group
             if (grp == ch / CPG) {
                 const int i = ch % CPG;
-                auto wr = [&](auto ec) {            // immediate offset: row (e & 3) + 8 (e >> 2) of the chunk
-                    constexpr int E = decltype(ec)::value;
-                    lds_write4<((E & 3) + 8 * (E >> 2)) * BN * 4>(scr_w, acc[i][E]);
-                };
-                wr(IC<0>{}); wr(IC<1>{}); wr(IC<2>{}); wr(IC<3>{}); wr(IC<4>{}); wr(IC<5>{}); wr(IC<6>{}); wr(IC<7>{});
-                wr(IC<8>{}); wr(IC<9>{}); wr(IC<10>{}); wr(IC<11>{}); wr(IC<12>{}); wr(IC<13>{}); wr(IC<14>{}); wr(IC<15>{});
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const unsigned w = scr_w + j * 128;
+                    auto wr = [&](auto ec) {            // immediate offset: row (e & 3) + 8 (e >> 2) of the chunk
+                        constexpr int E = decltype(ec)::value;
+                        lds_write4<((E & 3) + 8 * (E >> 2)) * BN * 4>(w, acc[i][j][E]);
+                    };
+                    wr(IC<0>{}); wr(IC<1>{}); wr(IC<2>{}); wr(IC<3>{}); wr(IC<4>{}); wr(IC<5>{}); wr(IC<6>{}); wr(IC<7>{});
+                    wr(IC<8>{}); wr(IC<9>{}); wr(IC<10>{}); wr(IC<11>{}); wr(IC<12>{}); wr(IC<13>{}); wr(IC<14>{}); wr(IC<15>{});
+                }
             }
-            if (res && ch + 1 < C::NCH) {
-                const unsigned char* rp = res_ptr(ch + 1);
-                rbuf[(ch + 1) & 1][0] = glb_read16(rp); rbuf[(ch + 1) & 1][1] = glb_read16(rp + 16);
-            }
+            if (res && ch + 1 < C::NCH) res_load(ch + 1);
             lgkm_wait0();                                       // this wave's scratch writes have landed
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
-            const int m = ti.m0 + ch * SCR_ROWS + r0;
-            const u32x4 w0 = lds_read16<0>(scr_r), w1 = lds_read16<16>(scr_r);
+            u32x4 w0[NPASS], w1[NPASS];
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                w0[ps] = (ps == 0) ? lds_read16<0>(scr_r) : lds_read16<(NPASS > 1 ? C::RPP * BN * 4 : 0)>(scr_r);
+                w1[ps] = (ps == 0) ? lds_read16<16>(scr_r) : lds_read16<(NPASS > 1 ? C::RPP * BN * 4 : 0) + 16>(scr_r);
+            }
             if (res) {
-                // residual of this chunk: younger vmem of this wave = the next chunk's 2 loads + the previous chunk's 2
-                // stores when every chunk stores (FULL); otherwise drain
+                // residual of this chunk: younger vmem of this wave = the next chunk's 2 NPASS loads + the previous chunk's
+                // 2 NPASS stores when every chunk stores (FULL); otherwise drain
                 if (FULL) {
-                    if (ch + 1 < C::NCH) { if (ch > 0) vmcnt_wait<4>(); else vmcnt_wait<2>(); }
-                    else { if (ch > 0) vmcnt_wait<2>(); else vmcnt_wait<0>(); }
+                    if (ch + 1 < C::NCH) { if (ch > 0) vmcnt_wait<4 * NPASS>(); else vmcnt_wait<2 * NPASS>(); }
+                    else { if (ch > 0) vmcnt_wait<2 * NPASS>(); else vmcnt_wait<0>(); }
                 } else vmcnt_wait<0>();
             }
             lgkm_wait0();
             __builtin_amdgcn_sched_barrier(0);
-            const f32x4 v0 = __builtin_bit_cast(f32x4, w0), v1 = __builtin_bit_cast(f32x4, w1);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
-            if (res) {
-                const u32x4 ra = rbuf[ch & 1][0], rb = rbuf[ch & 1][1];
-                if (p.res_fmt) {
-                    const h16x8 rh = __builtin_bit_cast(h16x8, ra), rl = __builtin_bit_cast(h16x8, rb);
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int m = ti.m0 + ch * SCR_ROWS + ps * C::RPP + r0;
+                const f32x4 v0 = __builtin_bit_cast(f32x4, w0[ps]), v1 = __builtin_bit_cast(f32x4, w1[ps]);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += ((float)rh[e] + (float)rl[e]) * res_mul;
-                } else {
-                    const f32x4 fa4 = __builtin_bit_cast(f32x4, ra), fb4 = __builtin_bit_cast(f32x4, rb);
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
+                if (res) {
+                    const u32x4 ra = rbuf[ch & 1][ps][0], rb = rbuf[ch & 1][ps][1];
+                    if (p.res_fmt) {
+                        const h16x8 rh = __builtin_bit_cast(h16x8, ra), rl = __builtin_bit_cast(h16x8, rb);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += fa4[e] * out_mul; v[4 + e] += fb4[e] * out_mul; }
-                }
-            }
-            if (p.relu) {
+                        for (int e = 0; e < 8; ++e) v[e] += ((float)rh[e] + (float)rl[e]) * res_mul;
+                    } else {
+                        const f32x4 fa4 = __builtin_bit_cast(f32x4, ra), fb4 = __builtin_bit_cast(f32x4, rb);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            if (FULL || (m < p.M && nok)) {
-                const int64_t orow = p.rowmap ? p.rowmap[m] : m;
-                unsigned char* cp = Cb + (orow * p.ldc + n) * 4;
-                if (p.c_fmt) {
-                    if (guard) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) vmax = fmaxf(vmax, fabsf(v[e]));
+                        for (int e = 0; e < 4; ++e) { v[e] += fa4[e] * out_mul; v[4 + e] += fb4[e] * out_mul; }
                     }
-                    uint2 h0, l0, h1, l1;
-                    split16(f32x4{v[0], v[1], v[2], v[3]}, h0, l0);
-                    split16(f32x4{v[4], v[5], v[6], v[7]}, h1, l1);
-                    *reinterpret_cast<uint4*>(cp) = uint4{h0.x, h0.y, h1.x, h1.y};
-                    *reinterpret_cast<uint4*>(cp + 16) = uint4{l0.x, l0.y, l1.x, l1.y};
-                } else {
-                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(cp + 16) = f32x4{v[4], v[5], v[6], v[7]};
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (FULL || (m < p.M && nok)) {
+                    const int64_t orow = p.rowmap ? p.rowmap[m] : m;
+                    unsigned char* cp = Cb + (orow * p.ldc + n) * 4;
+                    if (p.c_fmt) {
+                        if (guard) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) vmax = fmaxf(vmax, fabsf(v[e]));
+                        }
+                        uint2 h0, l0, h1, l1;
+                        split16(f32x4{v[0], v[1], v[2], v[3]}, h0, l0);
+                        split16(f32x4{v[4], v[5], v[6], v[7]}, h1, l1);
+                        *reinterpret_cast<uint4*>(cp) = uint4{h0.x, h0.y, h1.x, h1.y};
+                        *reinterpret_cast<uint4*>(cp + 16) = uint4{l0.x, l0.y, l1.x, l1.y};
+                    } else {
+                        *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(cp + 16) = f32x4{v[4], v[5], v[6], v[7]};
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -476,7 +523,9 @@ __global__ __launch_bounds__(NTHR) void gemm16_kernel(Gemm16Args p, int tiles_m,
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         if (grp == 1) __builtin_amdgcn_s_barrier();           // stagger: group 1's phases lag group 0's by one barrier
         const int c_end = c + nk;
         // two separate loops (one per flavour of the step): a single loop that picks the flavour per iteration made the
@@ -505,11 +554,11 @@ __global__ __launch_bounds__(NTHR) void gemm16_kernel(Gemm16Args p, int tiles_m,
     if (stamp) stamp[63] = __builtin_amdgcn_s_memrealtime() - stamp[62];
 }
 
-template <int BM, int CONV>
+template <int BM, int BN, int CONV>
 int launch_t(const Gemm16Args& a, hipStream_t st) {
-    using C = Cfg<BM>;
+    using C = Cfg<BM, BN>;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-    auto kern = gemm16_kernel<BM, CONV>;
+    auto kern = gemm16_kernel<BM, BN, CONV>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
@@ -524,9 +573,9 @@ int launch_t(const Gemm16Args& a, hipStream_t st) {
         char nm[128];
         static const bool by_shape = getenv("ACTMI_PROF_SHAPES") && getenv("ACTMI_PROF_SHAPES")[0] == '1';
         if (by_shape)
-            snprintf(nm, sizeof(nm), "gemm16_kernel<%d,%d>[M=%d,N=%d,K=%d,g=%d,sk=%d,wgs=%d]", BM, CONV, a.M, a.N, a.K, groups, splitk,
+            snprintf(nm, sizeof(nm), "gemm16_kernel<%d,%d,%d>[M=%d,N=%d,K=%d,g=%d,sk=%d,wgs=%d]", BM, BN, CONV, a.M, a.N, a.K, groups, splitk,
                      total);
-        else snprintf(nm, sizeof(nm), "gemm16_kernel<%d,%d>", BM, CONV);
+        else snprintf(nm, sizeof(nm), "gemm16_kernel<%d,%d,%d>", BM, BN, CONV);
         const double abytes = CONV ? (double)(a.M / (a.Ho * a.Wo)) * a.H * a.W * a.Cin : (double)a.M * a.K;
         prof_begin(nm, 2.0 * a.M * a.N * a.K * groups, 4.0 * groups * ((double)a.M * a.N + abytes + (double)a.N * a.K), st);
     }
@@ -543,6 +592,7 @@ int gemm16_pick_bm(int M, int N, int groups, int splitk) {
     // one workgroup per CU: a launch takes ceil(tiles / 256) rounds of (rows per tile) work; the 256-row tile moves a
     // third fewer operand bytes per MFMA, so it wins ties
     const long z = (long)(groups > 0 ? groups : 1) * (splitk > 1 ? splitk : 1);
+    constexpr int BN = 128;
     const long tn = (N + BN - 1) / BN;
     const long t128 = (long)((M + 127) / 128) * tn * z, t256 = (long)((M + 255) / 256) * tn * z;
     const double c128 = (double)((t128 + NUM_CU - 1) / NUM_CU) * 128 * 1.08, c256 = (double)((t256 + NUM_CU - 1) / NUM_CU) * 256;
@@ -576,11 +626,13 @@ int launch_gemm16(const Gemm16Args& a_in, hipStream_t st, std::string* err) {
         if (a.splitk > nk) return fail("every split must own at least one K tile");
         if (nk % a.splitk) return fail("every split must own the same number of K tiles (K / 32 divisible by splitk)");
     }
+    // bm: 128 / 256 = rows of a 128-column tile; 512 = the 256 x 256 tile (half the operand bytes per MFMA of 128 x 128)
     const int bm = a.bm ? a.bm : gemm16_pick_bm(a.M, a.N, a.groups, a.splitk);
     int rc;
-    if (bm == 256) rc = a.mode ? launch_t<256, 1>(a, st) : launch_t<256, 0>(a, st);
-    else if (bm == 128) rc = a.mode ? launch_t<128, 1>(a, st) : launch_t<128, 0>(a, st);
-    else return fail("bm must be 0, 128 or 256");
+    if (bm == 512) rc = a.mode ? launch_t<256, 256, 1>(a, st) : launch_t<256, 256, 0>(a, st);
+    else if (bm == 256) rc = a.mode ? launch_t<256, 128, 1>(a, st) : launch_t<256, 128, 0>(a, st);
+    else if (bm == 128) rc = a.mode ? launch_t<128, 128, 1>(a, st) : launch_t<128, 128, 0>(a, st);
+    else return fail("bm must be 0, 128, 256 or 512");
     if (rc != 0 && err) *err = std::string("gemm16 launch: ") + hipGetErrorString((hipError_t)rc);
     return rc == 0 ? 0 : -3;
 }

@@ -385,7 +385,36 @@ __global__ void amax_kernel(const float* __restrict__ x, int64_t ld, int M, int 
         m = max(m, __float_as_uint(x[r * ld + c]) & 0x7fffffffu);
     }
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(bits, m);
+    if ((threadIdx.x & 63) == 0 && m) amax_commit(bits, m);
+}
+
+// the same over 16-byte pieces (N, ld multiples of 4, 16-byte aligned base): four independent loads in flight per thread,
+// 32-bit index arithmetic (host: M * N / 4 < 2^31); FLAT: rows are contiguous (ld == N), no row / column split at all
+template <int FLAT>
+__global__ __launch_bounds__(256) void amax_vec_kernel(const actmi_f32x4* __restrict__ x, unsigned ld4, unsigned nv, unsigned total,
+                                                       unsigned* __restrict__ bits) {
+    const unsigned step = gridDim.x * 256u;
+    unsigned m = 0;
+    auto at = [&](unsigned i) -> actmi_f32x4 {
+        if (FLAT) return x[i];
+        const unsigned r = i / nv, c = i - r * nv;
+        return x[(uint64_t)r * ld4 + c];
+    };
+    auto acc = [&](const actmi_f32x4& v) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = max(m, __float_as_uint(v[e]) & 0x7fffffffu);
+    };
+    unsigned i = blockIdx.x * 256u + threadIdx.x;
+    for (; i + 3u * step < total && i + 3u * step >= i; i += 4u * step) {
+        const actmi_f32x4 v0 = at(i), v1 = at(i + step), v2 = at(i + 2u * step), v3 = at(i + 3u * step);
+        acc(v0); acc(v1); acc(v2); acc(v3);
+    }
+    for (; i < total; i += step) {
+        acc(at(i));
+        if (i + step < i) break;                           // 32-bit wrap (total close to 2^32)
+    }
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) amax_commit(bits, m);
 }
 
 __global__ void pow2_scale_kernel(unsigned* __restrict__ bits, float* __restrict__ out) {
@@ -397,16 +426,40 @@ __global__ void pow2_scale_kernel(unsigned* __restrict__ bits, float* __restrict
     *bits = 0;                                         // re-arm the slot
 }
 
+int launch_amax_bits(const float* x, int64_t ld, int M, int N, unsigned* bits, hipStream_t st) {
+    const int64_t total = (int64_t)M * N;
+    if (total <= 0) return 0;
+    const bool vec = (N & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)x & 15) == 0 && total / 4 < ((int64_t)1 << 31) &&
+                     (ld == N || ld / 4 < ((int64_t)1 << 31));
+    if (vec) {
+        const unsigned tv = (unsigned)(total / 4);
+        unsigned blocks = (tv + 256u * 4u - 1) / (256u * 4u);
+        if (blocks < 1) blocks = 1;
+        if (blocks > 4096) blocks = 4096;
+        const actmi_f32x4* xv = reinterpret_cast<const actmi_f32x4*>(x);
+        if (ld == N) hipLaunchKernelGGL(amax_vec_kernel<1>, dim3(blocks), dim3(256), 0, st, xv, 0u, (unsigned)(N / 4), tv, bits);
+        else hipLaunchKernelGGL(amax_vec_kernel<0>, dim3(blocks), dim3(256), 0, st, xv, (unsigned)(ld / 4), (unsigned)(N / 4), tv, bits);
+    } else {
+        int blocks = (int)((total + 256 * 16 - 1) / (256 * 16));
+        if (blocks < 1) blocks = 1;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, st, x, ld, M, N, bits);
+    }
+    return (int)hipGetLastError();
+}
+
+// scale from bits that a producing kernel already accumulated (its own atomicMax of |value| bits into out + 1)
+int launch_pow2_from_bits(float* out, hipStream_t st) {
+    hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned*>(out + 1), out);
+    return (int)hipGetLastError();
+}
+
 int launch_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, hipStream_t st) {
     // the word after the scale holds the running max bits (zero between uses)
     unsigned* bits = reinterpret_cast<unsigned*>(out + 1);
-    const int64_t total = (int64_t)M * N;
-    int blocks = (int)((total + 256 * 16 - 1) / (256 * 16));
-    if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, st, x, ld, M, N, bits);
-    hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, st, bits, out);
-    return (int)hipGetLastError();
+    const int rc = launch_amax_bits(x, ld, M, N, bits, st);
+    if (rc != 0) return rc;
+    return launch_pow2_from_bits(out, st);
 }
 
 namespace {

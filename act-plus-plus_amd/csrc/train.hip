@@ -110,10 +110,33 @@ const float* dyn_scale(actmi_ctx* ctx, const float* x, int64_t ld, int M, int N,
         T.amax_key_ptr = nullptr;
         return slot;
     }
+    if (T.amax_pre_ptr == x) {
+        // the kernel that wrote x accumulated the bits of its largest magnitude (amax_pre): no pass over x
+        float* slot = T.amax_pre_slot;
+        T.amax_pre_ptr = nullptr;
+        if (launch_pow2_from_bits(slot, st) != 0) return nullptr;
+        // always kept for one more request: these tensors feed a weight-gradient / data-gradient pair
+        T.amax_key_ptr = x; T.amax_key_ld = ld; T.amax_key_m = M; T.amax_key_n = N; T.amax_key_slot = slot;
+        return slot;
+    }
     float* slot = T.scale_slots + 2 * (T.scale_next++ % SCALE_SLOTS);
     if (launch_pow2_scale(x, ld, M, N, slot, st) != 0) return nullptr;
     T.amax_key_ptr = keep ? x : nullptr; T.amax_key_ld = ld; T.amax_key_m = M; T.amax_key_n = N; T.amax_key_slot = slot;
     return slot;
+}
+
+// The kernel that WRITES a gradient tensor can collect the amax bits itself (relu_bn_bwd, the GEMM epilogue: an integer
+// atomicMax, independent of arrival order): amax_pre() hands it the bits word of a fresh slot, and the dyn_scale() request
+// for that tensor then only derives the scale from it.  Returns nullptr when no scale will be asked for.
+unsigned* amax_pre(actmi_ctx* ctx, const float* out, hipStream_t st) {
+    if (ctx->gemm_prec != ACTMI_PREC_F16X3) return nullptr;
+    TrainState& T = *ctx->train;
+    if (T.amax_pre_ptr)          // an unclaimed registration: re-arm its word (does not happen on the paths below)
+        if (hipMemsetAsync(T.amax_pre_slot + 1, 0, sizeof(unsigned), st) != hipSuccess) return nullptr;
+    if (T.amax_key_ptr == out) T.amax_key_ptr = nullptr;         // the tensor is being rewritten
+    float* slot = T.scale_slots + 2 * (T.scale_next++ % SCALE_SLOTS);
+    T.amax_pre_ptr = out; T.amax_pre_slot = slot;
+    return reinterpret_cast<unsigned*>(slot + 1);
 }
 
 // weight operands of the backward GEMMs (f16x3) are split on the fly with the handle's static power-of-two scale
@@ -222,7 +245,7 @@ int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
     CHK(tgemm(ctx, d, st));
     // dS = P * (dP - delta) * scale   (in place of dP; with dropout dP = dPd * mask / (1-p))
     if (t.drop_p > 0.f) CHK(launch_attn_ds_drop(P, dP, T.delta, scale, t.drop_seed, t.drop_p, G, t.Nq, t.Nk, ldp, st));
-    else CHK(launch_attn_ds(P, dP, T.delta, scale, G, t.Nq, t.Nk, ldp, st));
+    else CHK(launch_attn_ds(P, dP, T.delta, scale, G, t.Nq, t.Nk, ldp, st, amax_pre(ctx, dP, st)));
     // dQ[q][d] = sum_key dS[q][key] K[key][d]
     GemmArgs q = G0();
     q.A = dP; q.lda = ldp; q.M = t.Nq; q.K = t.Nk; q.Bw = t.K; q.ldb = t.k_rs; q.tb = 1; q.N = t.HD;
@@ -344,7 +367,7 @@ int conv_wgrad(actmi_ctx* ctx, const ConvLayer& cl, int li, const float* dys, co
 
 // dx[C][B][H][W][cin] = dgrad(dys) (+res) , then masked by (mask > 0) and multiplied by scale[cin] (previous BN)
 int conv_dgrad(actmi_ctx* ctx, const ConvLayer& cl, int li, const float* dys, float* dx, const float* res, const float* mask,
-               const float* scale, int B, hipStream_t st) {
+               const float* scale, int B, hipStream_t st, bool dx_feeds_gemm = false) {
     TrainState& T = *ctx->train;
     const int C = ctx->cfg.num_cams;
     GemmArgs a = G0();
@@ -357,6 +380,7 @@ int conv_dgrad(actmi_ctx* ctx, const ConvLayer& cl, int li, const float* dys, fl
     a.scale = scale; a.gSB = cl.cin;
     a.b_scale = ctx->bwd_wscale;
     a.a_scale_dev = dyn_scale(ctx, dys, cl.cout, C * B * cl.Ho * cl.Wo, cl.cout, st, true);
+    if (dx_feeds_gemm) a.amax_out = amax_pre(ctx, dx, st);       // dx is the dY operand of the next wgrad / dgrad pair
     return tgemm(ctx, a, st);
 }
 
@@ -696,6 +720,7 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
     // and the finished gradient arena multiplied back (both exact); gradients already in the arena (accumulation
     // without zero_grad) are carried through the same scale.  Off by default -- see dyn_scale.
     T.amax_key_ptr = nullptr;
+    T.amax_pre_ptr = nullptr;
     float LS = 1.f;
     if (ctx->gemm_prec == ACTMI_PREC_F16X3) {
         static const char* ls_env = getenv("ACTMI_LOSS_SCALE_LOG2");
@@ -867,10 +892,10 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
         const float* x = bi > 0 ? T.blocks[bi - 1].out : T.pool;
         const int64_t per = (int64_t)B * k2.Ho * k2.Wo * k2.cout;
         // dz = dout * (out > 0) ; dzs = dz * scale_bn2 ; (downsample) dsc = dz * scale_ds
-        CHK(launch_relu_bn_bwd(gcur, nullptr, bs.out, k2.scale, dz, dzs, C, per, k2.cout, st));
+        CHK(launch_relu_bn_bwd(gcur, nullptr, bs.out, k2.scale, dz, dzs, C, per, k2.cout, st, amax_pre(ctx, dzs, st)));
         CHK(conv_wgrad(ctx, k2, bs.c2, dzs, bs.y1, B, st));
         // d(pre-bn1) = dgrad_conv2(dzs) * (y1 > 0) * scale_bn1
-        CHK(conv_dgrad(ctx, k2, bs.c2, dzs, dsc, nullptr, bs.y1, k1.scale, B, st));
+        CHK(conv_dgrad(ctx, k2, bs.c2, dzs, dsc, nullptr, bs.y1, k1.scale, B, st, true));
         CHK(conv_wgrad(ctx, k1, bs.c1, dsc, x, B, st));
         // dx = dgrad_conv1(dsc) + identity path
         float* dx = gcur;                     // gcur (dout) is dead after relu_bn_bwd
@@ -879,7 +904,7 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
         } else {
             const ConvLayer& ds = ctx->convs[bs.ds];
             CHK(conv_dgrad(ctx, k1, bs.c1, dsc, dx, nullptr, nullptr, nullptr, B, st));
-            CHK(launch_relu_bn_bwd(dz, nullptr, nullptr, ds.scale, nullptr, dzs, C, per, ds.cout, st));   // dzs = dz * scale_ds
+            CHK(launch_relu_bn_bwd(dz, nullptr, nullptr, ds.scale, nullptr, dzs, C, per, ds.cout, st, amax_pre(ctx, dzs, st)));   // dzs = dz * scale_ds
             CHK(conv_wgrad(ctx, ds, bs.ds, dzs, x, B, st));
             CHK(conv_dgrad(ctx, ds, bs.ds, dzs, dx, dx, nullptr, nullptr, B, st));
         }
@@ -887,7 +912,7 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
     // stem: maxpool, relu, bn1, conv1 weight gradient through the NHWC4 normalised image
     CHK(launch_maxpool_bwd_idx(T.pool_arg, gcur, T.g_act1, C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
     CHK(launch_relu_bn_bwd(T.g_act1, nullptr, ctx->act1, ctx->conv1_scale, nullptr, T.g_act1, C,
-                           (int64_t)B * ctx->H1 * ctx->W1 * w0, w0, st));
+                           (int64_t)B * ctx->H1 * ctx->W1 * w0, w0, st, amax_pre(ctx, T.g_act1, st)));
     {
         GemmArgs a = G0();
         a.A = T.g_act1; a.lda = w0; a.ta = 1; a.M = w0; a.K = B * ctx->H1 * ctx->W1;

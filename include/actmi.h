@@ -132,6 +132,11 @@ typedef struct actmi_gemm_desc {
      * atomics, C need not be zeroed, the fast epilogue applies); actmi_op_splitk_combine sums the slices in a fixed order
      * and applies scale / bias / residual / activation.  Every split must own at least one K tile of 32. */
     int64_t split_stride;
+    /* optional: the launch takes the integer maximum of the bits of |v| over every value it stores into *amax_out
+     * (non-negative floats order like unsigned integers; the word must be zero or hold an earlier maximum): what
+     * actmi_op_pow2_scale computes with a pass of its own, for the GEMM that reads this output next.  Meaningless with an
+     * atomic split-K (partial sums are stored). */
+    uint32_t* amax_out;
 } actmi_gemm_desc;
 
 /* GEMM / implicit-GEMM convolution on PRE-SPLIT operands (the inference path's form of actmi_gemm_desc with prec f16x3;

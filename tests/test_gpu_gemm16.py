@@ -32,7 +32,7 @@ def test_split16v2_round_trip_and_layout():
     assert torch.equal(halves[:, 8:], (xs - hi.double()).float().half().double())
 
 
-@pytest.mark.parametrize("bm", [128, 256])
+@pytest.mark.parametrize("bm", [128, 256, 512])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (1000, 136, 64), (1202, 1536, 512), (2404, 512, 3200), (300, 512, 4608),
                                    (77, 8, 96), (9616, 128, 128)])
 def test_gemm16_shapes(M, N, K, bm):
@@ -48,7 +48,7 @@ def test_gemm16_shapes(M, N, K, bm):
     assert torch.equal(got, again)
 
 
-@pytest.mark.parametrize("bm", [128, 256])
+@pytest.mark.parametrize("bm", [128, 256, 512])
 def test_gemm16_epilogue_forms(bm):
     """FrozenBN scale, bias, residual in both forms (s16 tensor; f32 table shared by the batch through row % res_mod), ReLU,
     s16 output with its own scale, row scatter, range flag."""
@@ -80,7 +80,7 @@ def test_gemm16_epilogue_forms(bm):
     assert int(flag.item()) == 1
 
 
-@pytest.mark.parametrize("bm", [128, 256])
+@pytest.mark.parametrize("bm", [128, 256, 512])
 @pytest.mark.parametrize("Cin,Cout,H,W,k,stride,pad", [(64, 128, 30, 40, 3, 2, 1), (128, 128, 15, 20, 3, 1, 1),
                                                        (64, 128, 30, 40, 1, 2, 0), (32, 64, 9, 7, 3, 1, 1)])
 def test_gemm16_convolution(Cin, Cout, H, W, k, stride, pad, bm):

@@ -39,7 +39,7 @@ for name, M, N, K in [("ffn1", 9616, 3200, 512), ("ffn2", 9616, 512, 3200), ("qk
     outf = torch.empty(M, N, device=D)
     r = {"name": name, "M": M, "N": N, "K": K, "gflop": 2.0 * M * N * K / 1e9}
     r["old_us"] = timeit(lambda: ops.gemm(A, W4, bias=b, prec="f16x3", w_split=256.0, out=outf))
-    for bm in (128, 256):
+    for bm in (128, 256, 512):
         r[f"g16_{bm}_us"] = timeit(lambda: ops.gemm16(A16, W16, alpha=1 / 4096.0, bias=b, out_scale=16.0, bm=bm, out=out16,
                                                       _ld_override=(0, 0) if HOT else None))
     rows.append(r)
@@ -56,13 +56,14 @@ for name, B, H, W_, Cin, Cout, k, s, p in [("l2_3x3", 8, 60, 80, 128, 128, 3, 1,
     out16 = torch.empty(G, B, Ho, Wo, Cout, device=D)
     r = {"name": name, "M": B * Ho * Wo, "N": Cout, "K": k * k * Cin, "groups": G, "gflop": 2.0 * G * B * Ho * Wo * Cout * k * k * Cin / 1e9}
     r["old_us"] = timeit(lambda: ops.conv2d_nhwc(x, w4, sc, bi, relu=True, stride=s, pad=p, prec="f16x3", w_split=256.0))
-    for bm in (128, 256):
+    for bm in (128, 256, 512):
         r[f"g16_{bm}_us"] = timeit(lambda: ops.gemm16(x16, w16, alpha=1 / 4096.0, scale=sc, bias=bi, relu=True, out_scale=16.0, bm=bm,
                                                       conv=dict(stride=s, pad=p), out=out16))
     rows.append(r)
 for r in rows:
-    for k in ("old_us", "g16_128_us", "g16_256_us"):
+    for k in ("old_us", "g16_128_us", "g16_256_us", "g16_512_us"):
         r[k.replace("_us", "_tf")] = r["gflop"] / r[k] * 1e3 / 1e3
     print(f"{r['name']:9s} M={r['M']:6d} N={r['N']:5d} K={r['K']:5d}  old {r['old_us']:7.1f} us {r['old_tf']:6.1f} TF | "
-          f"g16/128 {r['g16_128_us']:7.1f} us {r['g16_128_tf']:6.1f} TF | g16/256 {r['g16_256_us']:7.1f} us {r['g16_256_tf']:6.1f} TF", flush=True)
+          f"g16/128 {r['g16_128_us']:7.1f} us {r['g16_128_tf']:6.1f} TF | g16/256 {r['g16_256_us']:7.1f} us {r['g16_256_tf']:6.1f} TF | "
+          f"g16/256x256 {r['g16_512_us']:7.1f} us {r['g16_512_tf']:6.1f} TF", flush=True)
 json.dump(rows, open(os.path.join(ROOT, "gpurun_out", os.environ.get("G16_OUT", "gemm16_bench.json")), "w"), indent=1)
