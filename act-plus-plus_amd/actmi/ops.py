@@ -224,6 +224,20 @@ def conv3x3_c64(x, w_ohwi, scale=None, bias=None, res=None, relu=False, w_scale=
     return out
 
 
+def wgrad3x3_c64(dy, x, dy_scale=None):
+    """dW [G][64][3][3][64] (O, kh, kw, I) of the 64 -> 64 channel 3x3 / s1 / p1 convolution from dy, x [G][B][H][W][64]."""
+    G, B, H, W, Cc = x.shape
+    assert Cc == 64 and dy.shape == x.shape
+    nwg = max(1, min(256 // G, B * ((W + 31) // 32)))
+    ws = torch.empty(G * nwg * 64 * 576, device=x.device, dtype=torch.float32)
+    dw = torch.empty(G, 64, 3, 3, 64, device=x.device, dtype=torch.float32)
+    lib = L.load()
+    L.check(lib.actmi_op_wgrad3x3_c64(_p(dy.contiguous()), _p(x.contiguous()), _p(dw), _p(ws), ws.numel(),
+                                      _p(dy_scale) if dy_scale is not None else None, G, B, H, W, L.current_stream_ptr()),
+            None, "op_wgrad3x3_c64")
+    return dw
+
+
 def conv3x3_direct(x, w_ohwi, scale, bias, res=None, relu=False, w_scale=256.0):
     """direct 3x3 / stride 1 / pad 1 convolution, Cin and Cout multiples of 64 (f16x3): x [G,B,H,W,Cin], w_ohwi [G,Cout,3,3,Cin]."""
     lib = L.load()

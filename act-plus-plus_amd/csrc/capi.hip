@@ -297,6 +297,21 @@ int actmi_op_conv3x3_direct(const float* x, const float* w16, float w_scale, con
     return launch_conv3x3_direct(a, S(stream), &g_op_error);
 }
 
+int actmi_op_wgrad3x3_c64(const float* dy, const float* x, float* dw, float* ws, int64_t ws_floats, const float* dy_scale_dev, int G,
+                          int B, int H, int W, void* stream) {
+    g_op_error.clear();
+    int nwg = 0;
+    int rc = launch_wgrad3x3_c64(dy, x, ws, ws_floats, dy_scale_dev, G, B, H, W, &nwg, S(stream));
+    if (rc != 0) { g_op_error = "wgrad3x3_c64: bad arguments or launch failure"; return rc == -2 ? ACTMI_E_INVALID : ACTMI_E_LAUNCH; }
+    SplitCombineArgs c{};
+    const int64_t slice = (int64_t)64 * 576;
+    c.part = ws; c.nsplit = nwg; c.split_stride = slice; c.gP = slice * nwg; c.ldp = 576;
+    c.C = dw; c.ldc = 576; c.gC = slice; c.M = 64; c.N = 576; c.groups = G;
+    rc = launch_splitk_combine(c, S(stream));
+    if (rc != 0) { g_op_error = "wgrad3x3_c64: combine launch failed"; return ACTMI_E_LAUNCH; }
+    return 0;
+}
+
 const char* actmi_op_last_error(void) { return g_op_error.c_str(); }
 
 int actmi_set_gemm_prec(actmi_handle h, int prec) {

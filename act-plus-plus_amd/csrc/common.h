@@ -179,6 +179,10 @@ int launch_small_linear_wgrad(const float* dy, int64_t lddy, const float* x, int
 int launch_cvae_maps(int* map, uint8_t* kpm, const uint8_t* is_pad, int B, int Q, hipStream_t st);
 int launch_axpy(float* dst, const float* src, int64_t n, hipStream_t st);
 int launch_scale(float* x, int64_t n, float s, hipStream_t st);
+// direct weight gradient of the 64 -> 64 channel 3x3 / s1 / p1 convolutions (wgrad3.hip): per-workgroup partials
+// [groups][*nwg_out][64][576] into ws, to be summed by launch_splitk_combine
+int launch_wgrad3x3_c64(const float* dy, const float* x, float* ws, int64_t ws_floats, const float* dy_scale_dev, int groups, int B,
+                        int H, int W, int* nwg_out, hipStream_t st);
 int launch_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, hipStream_t st);
 int launch_pow2_from_bits(float* out, hipStream_t st);      // the scale from bits a producing kernel left in out[1]
 int launch_split16(const float* src, float* dst, int64_t nfloats, float scale, hipStream_t st, uint32_t* flag = nullptr);

@@ -353,6 +353,25 @@ int enc_bwd(actmi_ctx* ctx, const EncW& w, const EncSave& s, const float* dOut, 
 int conv_wgrad(actmi_ctx* ctx, const ConvLayer& cl, int li, const float* dys, const float* x, int B, hipStream_t st) {
     TrainState& T = *ctx->train;
     const int C = ctx->cfg.num_cams;
+    static const bool direct_on = !(getenv("ACTMI_WGRAD_DIRECT") && getenv("ACTMI_WGRAD_DIRECT")[0] == '0');
+    if (direct_on && ctx->gemm_prec == ACTMI_PREC_F16X3 && cl.cin == 64 && cl.cout == 64 && cl.k == 3 && cl.stride == 1 && cl.pad == 1 &&
+        T.det_ws && T.det_ws_floats >= (int64_t)C * 64 * 576) {
+        // layer1: the direct kernel (wgrad3.hip) + fixed-order sum of its per-workgroup partials into the packed gradient
+        const float* sc = dyn_scale(ctx, dys, cl.cout, C * B * cl.Ho * cl.Wo, cl.cout, st);
+        int nwg = 0;
+        if (launch_wgrad3x3_c64(dys, x, T.det_ws, T.det_ws_floats, sc, C, B, cl.H, cl.W, &nwg, st) != 0) {
+            ctx->err = "wgrad3x3_c64 launch failed";
+            return ACTMI_E_LAUNCH;
+        }
+        SplitCombineArgs c{};
+        const int64_t slice = (int64_t)64 * 576;
+        c.part = T.det_ws; c.nsplit = nwg; c.split_stride = slice; c.gP = slice * nwg; c.ldp = 576;
+        c.res = T.conv_gw[li]; c.ldres = cl.K; c.gRes = (int64_t)cl.cout * cl.K;         // accumulate like autograd
+        c.C = T.conv_gw[li]; c.ldc = cl.K; c.gC = (int64_t)cl.cout * cl.K;
+        c.M = 64; c.N = 576; c.groups = C;
+        if (launch_splitk_combine(c, st) != 0) { ctx->err = "splitk combine launch failed"; return ACTMI_E_LAUNCH; }
+        return 0;
+    }
     GemmArgs a = G0();
     a.A = dys; a.lda = cl.cout; a.ta = 1; a.M = cl.cout; a.K = B * cl.Ho * cl.Wo;
     a.Bw = x; a.tb = 2; a.N = cl.K; a.H = cl.H; a.W = cl.W; a.Cin = cl.cin; a.KH = a.KW = cl.k; a.stride = cl.stride;

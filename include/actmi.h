@@ -304,6 +304,14 @@ int actmi_op_conv3x3_c64(const float* x, const float* w16, float w_scale, const 
 int actmi_op_conv3x3_direct(const float* x, const float* w16, float w_scale, const float* scale, const float* bias,
                             const float* res, float* out, int G, int B, int H, int W, int Cin, int Cout, int relu, void* stream);
 
+/* weight gradient of the same 64 -> 64 channel 3x3 / s1 / p1 convolution (training path; torch.autograd of F.conv2d in
+ * torchvision's BasicBlock, reference backbone.py:95-134), f16x3 arithmetic: dw[G][64][(r,s,ci)] = sum over images and pixels of
+ * dy[G][B][H][W][64] x x[G][B][H][W][64] shifted by the tap.  ws: workspace of >= G * 64 * 576 * min(256 / G, B * ceil(W/32))
+ * floats (per-workgroup partials, summed in a fixed order: bitwise repeatable); dy_scale_dev: optional device power-of-two
+ * scale applied to dy before the fp16 split and undone in the result (actmi_op_pow2_scale). */
+int actmi_op_wgrad3x3_c64(const float* dy, const float* x, float* dw, float* ws, int64_t ws_floats, const float* dy_scale_dev, int G,
+                          int B, int H, int W, void* stream);
+
 /* ---- DiffusionPolicy inference path (reference policy.py:20-241, imitate_episodes.py:100-118,420-426).
  * The non-GEMM pieces of what the reference delegates to robomimic (ResNet18Conv with BatchNorm -> GroupNorm, SpatialSoftmax,
  * ConditionalUnet1D) and diffusers (DDIMScheduler.step); restated from the published definitions, parity unpinned (neither

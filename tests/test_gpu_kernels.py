@@ -358,3 +358,22 @@ def test_conv3x3_direct_matches_torch(G, B, H, W, Cin, Cout):
         assert rel_err(got[c], exp) < 2e-6
     plain = ops.conv3x3_direct(x.to(dev()), w.to(dev()), sc.to(dev()), bi.to(dev())).cpu()
     assert torch.equal(plain, ops.conv3x3_direct(x.to(dev()), w.to(dev()), sc.to(dev()), bi.to(dev())).cpu())
+
+
+@pytest.mark.parametrize("G,B,H,W", [(1, 1, 6, 32), (2, 3, 9, 37), (4, 2, 30, 40), (1, 2, 5, 70), (3, 1, 1, 1)])
+def test_wgrad3x3_c64_matches_torch(G, B, H, W):
+    """weight gradient of the layer1 convolutions on the direct kernel (strip walk, transposed staging, nine taps per staged
+    row) vs torch.nn.grad.conv2d_weight in fp64: map widths below / across / above the 32-pixel strip, single-row and
+    single-pixel maps, several images per group; with a device-side operand scale for tiny gradients; bitwise repeatable."""
+    g = torch.Generator().manual_seed(G * 100 + H + W)
+    x = torch.randn(G, B, H, W, 64, generator=g)
+    dy = torch.randn(G, B, H, W, 64, generator=g)
+    got = ops.wgrad3x3_c64(dy.to(dev()), x.to(dev())).cpu()
+    sc = torch.tensor([2.0 ** 20], device=dev())              # gradients of 1e-6: split after the device-side scale
+    got_s = ops.wgrad3x3_c64(dy.to(dev()) * 2.0 ** -20, x.to(dev()), dy_scale=sc).cpu()
+    for c in range(G):
+        exp = torch.nn.grad.conv2d_weight(x[c].permute(0, 3, 1, 2).double(), (64, 64, 3, 3), dy[c].permute(0, 3, 1, 2).double(),
+                                          padding=1).permute(0, 2, 3, 1)          # [O][kh][kw][I]
+        assert rel_err(got[c], exp) < 2e-6
+    assert torch.equal(got_s, got * 2.0 ** -20)
+    assert torch.equal(got, ops.wgrad3x3_c64(dy.to(dev()), x.to(dev())).cpu())
