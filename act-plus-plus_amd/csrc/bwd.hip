@@ -270,6 +270,15 @@ __global__ __launch_bounds__(256) void attn_probs_vec_kernel(f32x4* __restrict__
     }
 }
 
+// x[r][c0 .. ld) = 0 for every row (the pad columns of the probability buffers)
+__global__ void zero_cols_kernel(float* __restrict__ x, int64_t rows, int ld, int c0) {
+    const int w = ld - c0;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * w) return;
+    const int64_t r = i / w;
+    x[r * ld + c0 + (int)(i - r * w)] = 0.f;
+}
+
 // dS = P * (dP - delta[g][q]) * scale, in place of dP
 __global__ void attn_ds_kernel(const float* __restrict__ P, float* __restrict__ dP, const float* __restrict__ delta,
                                float scale, int Nk, int ldp, int64_t total) {
@@ -656,6 +665,13 @@ int launch_attn_probs(float* S, const float* lse, const uint8_t* kpm, int64_t kp
         hipLaunchKernelGGL(attn_probs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, S, lse, kpm, kpm_bs, H, Nq,
                            Nk, ldp, total);
     prof_end(st);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_zero_cols(float* x, int64_t rows, int ld, int c0, hipStream_t st) {
+    if (c0 >= ld || rows <= 0) return 0;
+    const int64_t total = rows * (ld - c0);
+    hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, rows, ld, c0);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

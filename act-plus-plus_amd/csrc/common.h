@@ -150,6 +150,7 @@ int launch_sum_batch(const float* src, int64_t bs, int64_t ld, float* dst, int B
 int launch_attn_delta(const float* dO, const float* O, float* delta, int B, int H, int Nq, int HD, hipStream_t st);
 int launch_attn_probs(float* S, const float* lse, const uint8_t* kpm, int64_t kpm_bs, int G, int H, int Nq, int Nk, int ldp,
                       hipStream_t st);
+int launch_zero_cols(float* x, int64_t rows, int ld, int c0, hipStream_t st);
 int launch_attn_ds(const float* P, float* dP, const float* delta, float scale, int G, int Nq, int Nk, int ldp,
                    hipStream_t st, unsigned* amax_bits = nullptr);
 // losses: [3] results followed by >= 513 floats of scratch (block partials of the l1 sum: fixed-order total)

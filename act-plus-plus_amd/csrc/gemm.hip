@@ -695,14 +695,29 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
         if (p.a_scale_dev) alpha /= *p.a_scale_dev;
         if (!BSPLIT && p.b_scale_dev) alpha /= *p.b_scale_dev;
     }
-    const bool has_res = res != nullptr, has_mask = mask != nullptr, has_map = p.rowmap != nullptr;
+    const bool has_mask = mask != nullptr, has_map = p.rowmap != nullptr;
+    // fused attention-backward epilogues (actmi.h: epi): a per-row vector, a per-column kill mask, res as a factor
+    const int epi = p.epi;
+    const float* erow = nullptr;
+    const uint8_t* ekill = nullptr;
+    if (epi != 0) {
+        if (p.groups_inner > 0) {
+            const int g1 = g / p.groups_inner, g2 = g % p.groups_inner;
+            erow = p.epi_row + g1 * p.gRow + g2 * p.gRow2;
+            ekill = p.epi_colkill ? p.epi_colkill + g1 * p.gColkill : nullptr;
+        } else {
+            erow = p.epi_row + (int64_t)g * p.gRow;
+            ekill = p.epi_colkill ? p.epi_colkill + (int64_t)g * p.gColkill : nullptr;
+        }
+    }
+    const bool has_res = res != nullptr && epi != 2;          // epi 2 multiplies by res instead of adding it
     const float drop_scale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
     // Fast epilogue for the forward-pass cases (bias / FrozenBN affine, optional same-shape residual, optional ReLU): the
     // feature-complete path below costs ~140 instructions per element (per-element branches, 64-bit index arithmetic) and
     // was measured at 45-75k cycles per 128x128 tile, a quarter of a K=512 main loop; this one is a few thousand.
     const bool simple = !has_map && (splitk <= 1 || p.split_stride != 0) && !C2 && !(p.drop_p > 0.f) && p.res_mod == 0 &&
                         (!has_mask || (int64_t)p.M * ldmask < (int64_t)1 << 31) &&
-                        (int64_t)p.M * p.ldc < (int64_t)1 << 31 && (!has_res || (int64_t)p.M * p.ldres < (int64_t)1 << 31);
+                        (int64_t)p.M * p.ldc < (int64_t)1 << 31 && (!res || (int64_t)p.M * p.ldres < (int64_t)1 << 31);
     unsigned amx = 0;                  // bits of max |stored value| (p.amax_out)
     auto amax_flush = [&]() {
         if (!p.amax_out) return;
@@ -717,7 +732,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
         // covering whole 128-byte lines.  (The scalar form below writes 4 bytes per lane; its store burst was measured
         // at ~2.7 TB/s chip-wide against ~6 TB/s for contiguous 16-byte stores.)
         const bool vec = n0 + BN <= p.N && (p.ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
-                         (!has_res || ((p.ldres & 3) == 0 && ((uintptr_t)res & 15) == 0)) &&
+                         (!res || ((p.ldres & 3) == 0 && ((uintptr_t)res & 15) == 0)) &&
                          (!has_mask || ((ldmask & 3) == 0 && ((uintptr_t)mask & 15) == 0)) &&
                          (!scale || ((uintptr_t)scale & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
         if (vec) {
@@ -746,6 +761,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                     f32x4 v = *reinterpret_cast<const f32x4*>(scr + r * RS + c4 * 4);
                     v = v * alpha * sc4 + bi4;
                     if (m < p.M) {
+                        if (epi == 1) {
+                            const float rsub = erow[m];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = (ekill && ekill[ncol + e] != 0) ? 0.f : expf(v[e] - rsub);
+                        } else if (epi == 2) {
+                            const f32x4 pr = ld4(res + (uint32_t)(m * (int)p.ldres + ncol));
+                            v = pr * (v - erow[m]) * p.epi_scale;
+                        }
                         if (has_res) v += ld4(res + (uint32_t)(m * (int)p.ldres + ncol));
                         if (has_mask) {
                             const f32x4 mk = ld4(mask + (uint32_t)(m * (int)ldmask + ncol));
@@ -794,6 +817,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                 for (int e = 0; e < 16; ++e) {
                     const int m = mb + (e & 3) + 8 * (e >> 2);
                     float v = acc[i][j][e] * alpha * sc + bi;
+                    if (epi != 0 && nok && m < p.M) {
+                        if (epi == 1) v = (ekill && ekill[n] != 0) ? 0.f : expf(v - erow[m]);
+                        else v = res[(uint32_t)(m * (int)p.ldres + n)] * (v - erow[m]) * p.epi_scale;
+                    }
                     if (has_res) v += rv[e];
                     if (has_mask && nok && m < p.M) { if (!(mask[(uint32_t)(m * (int)ldmask + n)] > 0.f)) v = 0.f; }
                     v = relu ? fmaxf(v, 0.f) : v;

@@ -219,8 +219,18 @@ int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
     s.A = t.Q; s.lda = t.q_rs; s.M = t.Nq; s.K = t.HD; s.Bw = t.K; s.ldb = t.k_rs; s.N = t.Nk; s.C = P; s.ldc = ldp;
     s.alpha = scale; s.groups = G; s.groups_inner = t.H;
     s.gA = t.q_bs; s.gA2 = t.HD; s.gB = t.k_bs; s.gB2 = t.HD; s.gC = pg * t.H; s.gC2 = pg;
-    CHK(tgemm(ctx, s, st));
-    CHK(launch_attn_probs(P, t.lse, t.kpm, t.kpm_bs, G, t.H, t.Nq, t.Nk, ldp, st));
+    // P = exp(S - lse) (key-padded columns zero) straight from the epilogue of the score product; the columns Nk .. ldp-1 of
+    // the buffer are cleared by a small kernel (the buffer is shared by attention calls of different widths)
+    static const bool fuse = !(getenv("ACTMI_ATTN_BWD_FUSE") && getenv("ACTMI_ATTN_BWD_FUSE")[0] == '0');
+    if (fuse) {
+        s.epi = 1; s.epi_row = t.lse; s.gRow = (int64_t)t.H * t.Nq; s.gRow2 = t.Nq;
+        s.epi_colkill = t.kpm; s.gColkill = t.kpm_bs;
+        CHK(tgemm(ctx, s, st));
+        if (ldp != t.Nk) CHK(launch_zero_cols(P, (int64_t)G * t.Nq, ldp, t.Nk, st));
+    } else {
+        CHK(tgemm(ctx, s, st));
+        CHK(launch_attn_probs(P, t.lse, t.kpm, t.kpm_bs, G, t.H, t.Nq, t.Nk, ldp, st));
+    }
     CHK(launch_attn_delta(t.dO, t.O, T.delta, t.B, t.H, t.Nq, t.HD, st));
     // dV[key][d] = sum_q Pd[q][key] dO[q][d]   (Pd = dropped weights; staged in the dP buffer before dP overwrites it)
     const float* Pv = P;
@@ -242,10 +252,21 @@ int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
     d.groups = G; d.groups_inner = t.H;
     d.gA = (int64_t)t.Nq * D; d.gA2 = t.HD; d.gB = t.v_bs; d.gB2 = t.HD; d.gC = pg * t.H; d.gC2 = pg;
     d.a_scale_dev = dO_sc;
-    CHK(tgemm(ctx, d, st));
-    // dS = P * (dP - delta) * scale   (in place of dP; with dropout dP = dPd * mask / (1-p))
-    if (t.drop_p > 0.f) CHK(launch_attn_ds_drop(P, dP, T.delta, scale, t.drop_seed, t.drop_p, G, t.Nq, t.Nk, ldp, st));
-    else CHK(launch_attn_ds(P, dP, T.delta, scale, G, t.Nq, t.Nk, ldp, st, amax_pre(ctx, dP, st)));
+    const bool fuse_ds = fuse && !(t.drop_p > 0.f);
+    if (fuse_ds) {
+        // dS = P * (dP - delta) * scale in the epilogue of the dP product (dP itself is never stored), with the operand-scale
+        // maximum of dS collected on the way out
+        d.epi = 2; d.epi_scale = scale; d.epi_row = T.delta; d.gRow = (int64_t)t.H * t.Nq; d.gRow2 = t.Nq;
+        d.res = P; d.ldres = ldp; d.gRes = pg * t.H; d.gRes2 = pg;
+        d.amax_out = amax_pre(ctx, dP, st);
+        CHK(tgemm(ctx, d, st));
+        if (ldp != t.Nk) CHK(launch_zero_cols(dP, (int64_t)G * t.Nq, ldp, t.Nk, st));
+    } else {
+        CHK(tgemm(ctx, d, st));
+        // dS = P * (dP - delta) * scale   (in place of dP; with dropout dP = dPd * mask / (1-p))
+        if (t.drop_p > 0.f) CHK(launch_attn_ds_drop(P, dP, T.delta, scale, t.drop_seed, t.drop_p, G, t.Nq, t.Nk, ldp, st));
+        else CHK(launch_attn_ds(P, dP, T.delta, scale, G, t.Nq, t.Nk, ldp, st, amax_pre(ctx, dP, st)));
+    }
     // dQ[q][d] = sum_key dS[q][key] K[key][d]
     GemmArgs q = G0();
     q.A = dP; q.lda = ldp; q.M = t.Nq; q.K = t.Nk; q.Bw = t.K; q.ldb = t.k_rs; q.tb = 1; q.N = t.HD;

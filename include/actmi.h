@@ -137,6 +137,19 @@ typedef struct actmi_gemm_desc {
      * actmi_op_pow2_scale computes with a pass of its own, for the GEMM that reads this output next.  Meaningless with an
      * atomic split-K (partial sums are stored). */
     uint32_t* amax_out;
+    /* fused attention-backward epilogues (training path; fast epilogue forms only, no row map / C2 / dropout):
+     *   epi = 1: C = exp(v - epi_row[m]), zero where epi_colkill[n] != 0   (v = alpha * acc: softmax probabilities from the
+     *            scores and the saved log-sum-exp; epi_colkill = key padding mask, optional)
+     *   epi = 2: C = res[m][n] * (v - epi_row[m]) * epi_scale              (dS = P * (dP - delta) * scale; res is a factor here,
+     *            not an addend)
+     * epi_row: per-row vector of the group, group strides gRow (first level) / gRow2 (second level, with groups_inner);
+     * epi_colkill: bytes per column, first-level group stride gColkill (second level shares it). */
+    int32_t epi;
+    float epi_scale;
+    const float* epi_row;
+    int64_t gRow, gRow2;
+    const uint8_t* epi_colkill;
+    int64_t gColkill;
 } actmi_gemm_desc;
 
 /* GEMM / implicit-GEMM convolution on PRE-SPLIT operands (the inference path's form of actmi_gemm_desc with prec f16x3;
