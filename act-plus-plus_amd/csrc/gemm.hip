@@ -697,7 +697,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
     }
     const bool has_mask = mask != nullptr, has_map = p.rowmap != nullptr;
     // fused attention-backward epilogues (actmi.h: epi): a per-row vector, a per-column kill mask, res as a factor
-    const int epi = p.epi;
+    const int epi = UNMASKED ? 0 : p.epi;          // the hot forward flavour carries neither these epilogues nor the amax
     const float* erow = nullptr;
     const uint8_t* ekill = nullptr;
     if (epi != 0) {
@@ -719,10 +719,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                         (!has_mask || (int64_t)p.M * ldmask < (int64_t)1 << 31) &&
                         (int64_t)p.M * p.ldc < (int64_t)1 << 31 && (!res || (int64_t)p.M * p.ldres < (int64_t)1 << 31);
     unsigned amx = 0;                  // bits of max |stored value| (p.amax_out)
+    unsigned* const amax_out = UNMASKED ? nullptr : p.amax_out;
     auto amax_flush = [&]() {
-        if (!p.amax_out) return;
+        if (!amax_out) return;
         for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
-        if (lane == 0 && amx) amax_commit(p.amax_out, amx);
+        if (lane == 0 && amx) amax_commit(amax_out, amx);
     };
     if (simple) {
         const bool relu = p.relu == 1, gelu = p.relu == 2;
@@ -784,7 +785,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                             for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
                         }
                         *reinterpret_cast<f32x4*>(C + (uint32_t)(m * (int)p.ldc + ncol)) = v;
-                        if (p.amax_out) {
+                        if (amax_out) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) amx = max(amx, __float_as_uint(v[e]) & 0x7fffffffu);
                         }
@@ -827,7 +828,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                     if (gelu) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
                     if (nok && m < p.M) {
                         C[(uint32_t)(m * (int)p.ldc + n)] = v;
-                        if (p.amax_out) amx = max(amx, __float_as_uint(v) & 0x7fffffffu);
+                        if (amax_out) amx = max(amx, __float_as_uint(v) & 0x7fffffffu);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -882,7 +883,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (splitk > 1 && p.split_stride == 0) atomicAdd(&C[o], v);
                     else C[o] = v;
-                    if (p.amax_out) amx = max(amx, __float_as_uint(v) & 0x7fffffffu);
+                    if (amax_out) amx = max(amx, __float_as_uint(v) & 0x7fffffffu);
                     if (C2) C2[o] = v * sc2;
                 }
             }
@@ -937,7 +938,7 @@ int launch_cfg_b(const GemmArgs& a, hipStream_t st) {
     if constexpr (HOT) {
         const bool one_a = (a.a_scale == 0.f || a.a_scale == 1.f) && !a.a_scale_dev;
         const bool one_b = BSPLIT || ((a.b_scale == 0.f || a.b_scale == 1.f) && !a.b_scale_dev);
-        if ((a.K % BK) == 0 && one_a && one_b) return launch_cfg_u<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, 1>(a, st);
+        if ((a.K % BK) == 0 && one_a && one_b && a.epi == 0 && !a.amax_out) return launch_cfg_u<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, 1>(a, st);
     }
     return launch_cfg_u<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, 0>(a, st);
 }
