@@ -45,7 +45,7 @@ class GemmDesc(C.Structure):
         ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("stamps", C.c_void_p), ("prec", C.c_int32), ("b_split", C.c_int32), ("b_scale", C.c_float), ("a_scale", C.c_float), ("a_scale_dev", C.c_void_p), ("b_scale_dev", C.c_void_p),
         ("split_stride", C.c_int64), ("amax_out", C.c_void_p),
         ("epi", C.c_int32), ("epi_scale", C.c_float), ("epi_row", C.c_void_p), ("gRow", C.c_int64), ("gRow2", C.c_int64),
-        ("epi_colkill", C.c_void_p), ("gColkill", C.c_int64),
+        ("epi_colkill", C.c_void_p), ("gColkill", C.c_int64), ("tile_hint", C.c_int32),
     ]
 
 

@@ -416,8 +416,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 // [G][O][(r,s,c)] forward-packed conv weight -> [G][C][(r,s,o)] for the data gradient (n fastest in the contraction)
+// flip: the taps reversed (rs -> KK-1-rs): the data gradient of a stride-1 convolution as a forward convolution of dY
 __global__ void repack_dgrad_w_kernel(const float* __restrict__ wf, float* __restrict__ wd, int O, int I, int KK,
-                                      int64_t total) {
+                                      int64_t total, int flip) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int o = (int)(idx % O);
@@ -425,7 +426,7 @@ __global__ void repack_dgrad_w_kernel(const float* __restrict__ wf, float* __res
     const int rs = (int)(rest % KK); rest /= KK;
     const int c = (int)(rest % I);
     const int64_t g = rest / I;
-    wd[idx] = wf[((g * O + o) * KK + rs) * I + c];
+    wd[idx] = wf[((g * O + o) * KK + (flip ? KK - 1 - rs : rs)) * I + c];
 }
 
 // wgrad comes out as [G][O][(r,s,c)]; the state_dict gradient is OIHW
@@ -792,9 +793,9 @@ int launch_adamw(float* p, const float* g, float* m, float* v, const uint8_t* gr
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int launch_repack_dgrad_w(const float* wf, float* wd, int G, int O, int I, int KK, hipStream_t st) {
+int launch_repack_dgrad_w(const float* wf, float* wd, int G, int O, int I, int KK, hipStream_t st, int flip) {
     const int64_t total = (int64_t)G * I * KK * O;
-    hipLaunchKernelGGL(repack_dgrad_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wf, wd, O, I, KK, total);
+    hipLaunchKernelGGL(repack_dgrad_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wf, wd, O, I, KK, total, flip);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

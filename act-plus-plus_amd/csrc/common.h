@@ -86,6 +86,13 @@ struct Conv3Args {
     float* out;           // [G][B][H][W][64]
     int G, B, H, W, relu;
     float w_scale;
+    // data-gradient use (training): the input is a gradient map with a device-side power-of-two scale (applied before the
+    // fp16 split, undone in the result); the result is zeroed where mask <= 0 (ReLU backward; same shape as out) and then
+    // multiplied by post_scale[G][64] (the FrozenBN scale of the layer below); amax_out collects the bits of max |out|
+    const float* x_scale_dev = nullptr;
+    const float* mask = nullptr;
+    const float* post_scale = nullptr;
+    unsigned* amax_out = nullptr;
 };
 int launch_conv3x3_c64(const Conv3Args& a, hipStream_t st, std::string* err);
 
@@ -168,7 +175,7 @@ int launch_vq_code(const float* logits, const float* code_in, uint64_t seed, flo
 int launch_vq_bwd(const float* probs, const float* g, float* dlogits, int B, int VC, int VD, hipStream_t st);
 int launch_adamw(float* p, const float* g, float* m, float* v, const uint8_t* group, int64_t n, float lr, float lr_bb,
                  float wd, float b1, float b2, float eps, int64_t step, hipStream_t st);
-int launch_repack_dgrad_w(const float* wf, float* wd, int G, int O, int I, int KK, hipStream_t st);
+int launch_repack_dgrad_w(const float* wf, float* wd, int G, int O, int I, int KK, hipStream_t st, int flip = 0);
 int launch_unpack_wgrad(const float* gp, float* g_oihw, int O, int I, int KH, int KW, int kpad, int ipack, hipStream_t st);
 int launch_relu_bn_bwd(const float* x, const float* add, const float* mask, const float* scale, float* y_plain,
                        float* y_scaled, int G, int64_t per_group, int C, hipStream_t st, unsigned* amax_bits = nullptr);

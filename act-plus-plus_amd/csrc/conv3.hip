@@ -79,6 +79,9 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_f16x3_kernel(Conv3Args p, in
     // ---- input patch: 10 x 34 pixels x 16 float4 groups, zero outside the image; split on the way in.  All of a thread's
     //      loads are issued before the first is consumed (a rolled loop serialised ~11 global round trips per tile).
     constexpr int NP = (PR * PW * 16 + NTHR - 1) / NTHR;
+    const float xs = p.x_scale_dev ? *p.x_scale_dev : 1.f;        // (gradient maps: operand scale of the data-gradient use)
+    // running maximum read at the start (a lower bound that only filters the atomics at the end: common.h amax_commit)
+    const unsigned amax_seen = p.amax_out ? __hip_atomic_load(p.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     f32x4 pv[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_f16x3_kernel(Conv3Args p, in
         if (e < PR * PW * 16) {
             const int grp = e & 15, pix = e >> 4;
             uint2 hv, lv;
-            split16(pv[i], hv, lv);
+            split16(pv[i] * xs, hv, lv);
             *reinterpret_cast<uint2*>(s_patch + pix * PIX + grp * 8) = hv;
             *reinterpret_cast<uint2*>(s_patch + pix * PIX + 128 + grp * 8) = lv;
         }
@@ -159,9 +162,12 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_f16x3_kernel(Conv3Args p, in
             scr[((e & 3) + 8 * (e >> 2) + 4 * lh) * RS + nt * 32 + li] = acc[nt][e];
     if (ho >= p.H) return;
     const int c4 = lane & 15, pq = lane >> 4;                     // channel group of 4, pixel within a group of 4
-    const float inv = 1.f / p.w_scale;
-    const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + g * CH + c4 * 4) * inv;
-    const f32x4 bi4 = *reinterpret_cast<const f32x4*>(p.bias + g * CH + c4 * 4);
+    const float inv = 1.f / (p.w_scale * xs);
+    const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 sc4 = (p.scale ? *reinterpret_cast<const f32x4*>(p.scale + g * CH + c4 * 4) : one4) * inv;
+    const f32x4 bi4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + g * CH + c4 * 4) : zero4;
+    const f32x4 ps4 = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_scale + g * CH + c4 * 4) : one4;
+    unsigned amx = 0;
     const int64_t rowbase = ((img * p.H + ho) * (int64_t)p.W) * CH + c4 * 4;
     f32x4 rv[8];
     if (p.res) {
@@ -180,7 +186,21 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_f16x3_kernel(Conv3Args p, in
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if (wo < p.W) *reinterpret_cast<f32x4*>(p.out + rowbase + (int64_t)wo * CH) = v;
+        if (wo < p.W) {
+            if (p.mask) {
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + rowbase + (int64_t)wo * CH);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+            }
+            v = v * ps4;
+            *reinterpret_cast<f32x4*>(p.out + rowbase + (int64_t)wo * CH) = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amx = max(amx, __float_as_uint(v[e]) & 0x7fffffffu);
+        }
+    }
+    if (p.amax_out) {
+        for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
+        if (lane == 0 && amx > amax_seen) atomicMax(p.amax_out, amx);
     }
 }
 

@@ -54,6 +54,7 @@ struct TrainState {
     float* conv1_gw = nullptr;
     std::vector<BlockSave> blocks;
     std::vector<float*> conv_gw, conv_wd;
+    std::vector<float*> conv_wd16;                 // layer1 (64 -> 64, 3x3 / s1): split image of the flipped data-gradient weights, else NULL
     // transformer
     std::vector<EncSave> en, cv;
     float *mem = nullptr, *Xc = nullptr, *cv_out = nullptr;

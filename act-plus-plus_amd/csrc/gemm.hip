@@ -136,6 +136,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
         const unsigned xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
         stamp[1] = ((uint64_t)xcc << 32) | hw;
     }
+    unsigned* const amax_out = UNMASKED ? nullptr : p.amax_out;
+    const unsigned amax_seen = amax_out ? __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     const int nk_total = (p.K + BK - 1) / BK;
     const int tps = (nk_total + splitk - 1) / splitk;
     const int kt_begin = split * tps;
@@ -719,11 +721,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                         (!has_mask || (int64_t)p.M * ldmask < (int64_t)1 << 31) &&
                         (int64_t)p.M * p.ldc < (int64_t)1 << 31 && (!res || (int64_t)p.M * p.ldres < (int64_t)1 << 31);
     unsigned amx = 0;                  // bits of max |stored value| (p.amax_out)
-    unsigned* const amax_out = UNMASKED ? nullptr : p.amax_out;
     auto amax_flush = [&]() {
         if (!amax_out) return;
         for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
-        if (lane == 0 && amx) amax_commit(amax_out, amx);
+        // amax_seen was read when the block started (a lower bound of the running maximum: it only filters): no load
+        // latency at the tail of every tile
+        if (lane == 0 && amx > amax_seen) atomicMax(amax_out, amx);
     };
     if (simple) {
         const bool relu = p.relu == 1, gelu = p.relu == 2;
@@ -992,6 +995,9 @@ int launch_modes(const GemmArgs& a, hipStream_t st) {
     if (force && force[0] == 'L') return launch_cfg<128, 128, 64, 64, AMODE, BMODE, PREC>(a, st);
     if (force && force[0] == 'M') return launch_cfg<128, 64, 64, 32, AMODE, BMODE, PREC>(a, st);
     if (force && force[0] == 'S') return launch_cfg<64, 64, 32, 32, AMODE, BMODE, PREC>(a, st);
+    if (a.tile_hint == 1) return launch_cfg<128, 128, 64, 64, AMODE, BMODE, PREC>(a, st);
+    if (a.tile_hint == 2) return launch_cfg<128, 64, 64, 32, AMODE, BMODE, PREC>(a, st);
+    if (a.tile_hint == 3) return launch_cfg<64, 64, 32, 32, AMODE, BMODE, PREC>(a, st);
     if (eL >= eM && eL >= eS) return launch_cfg<128, 128, 64, 64, AMODE, BMODE, PREC>(a, st);
     if (eM >= eS) return launch_cfg<128, 64, 64, 32, AMODE, BMODE, PREC>(a, st);
     return launch_cfg<64, 64, 32, 32, AMODE, BMODE, PREC>(a, st);

@@ -222,6 +222,8 @@ int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
     // P = exp(S - lse) (key-padded columns zero) straight from the epilogue of the score product; the columns Nk .. ldp-1 of
     // the buffer are cleared by a small kernel (the buffer is shared by attention calls of different widths)
     static const bool fuse = !(getenv("ACTMI_ATTN_BWD_FUSE") && getenv("ACTMI_ATTN_BWD_FUSE")[0] == '0');
+    static const int sd_tile = getenv("ACTMI_ATTN_BWD_TILE") ? atoi(getenv("ACTMI_ATTN_BWD_TILE")) : 0;
+    s.tile_hint = sd_tile;
     if (fuse) {
         s.epi = 1; s.epi_row = t.lse; s.gRow = (int64_t)t.H * t.Nq; s.gRow2 = t.Nq;
         s.epi_colkill = t.kpm; s.gColkill = t.kpm_bs;
@@ -252,6 +254,7 @@ int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
     d.groups = G; d.groups_inner = t.H;
     d.gA = (int64_t)t.Nq * D; d.gA2 = t.HD; d.gB = t.v_bs; d.gB2 = t.HD; d.gC = pg * t.H; d.gC2 = pg;
     d.a_scale_dev = dO_sc;
+    d.tile_hint = sd_tile;
     const bool fuse_ds = fuse && !(t.drop_p > 0.f);
     if (fuse_ds) {
         // dS = P * (dP - delta) * scale in the epilogue of the dP product (dP itself is never stored), with the operand-scale
@@ -405,11 +408,27 @@ int conv_wgrad(actmi_ctx* ctx, const ConvLayer& cl, int li, const float* dys, co
     return tgemm(ctx, a, st);
 }
 
+// layer1's data gradients (64 -> 64 channels, 3x3 / s1 / p1) run as a forward convolution of dY with the flipped, transposed
+// weights on the direct kernel of the inference path (conv3.hip: LDS-resident patch, 1.3 ms against the gather GEMM's 2.5 ms)
+bool dgrad_direct(const actmi_ctx* ctx, const ConvLayer& cl) {
+    static const bool on = !(getenv("ACTMI_DGRAD_DIRECT") && getenv("ACTMI_DGRAD_DIRECT")[0] == '0');
+    return on && ctx->gemm_prec == ACTMI_PREC_F16X3 && cl.cin == 64 && cl.cout == 64 && cl.k == 3 && cl.stride == 1 && cl.pad == 1;
+}
+
 // dx[C][B][H][W][cin] = dgrad(dys) (+res) , then masked by (mask > 0) and multiplied by scale[cin] (previous BN)
 int conv_dgrad(actmi_ctx* ctx, const ConvLayer& cl, int li, const float* dys, float* dx, const float* res, const float* mask,
                const float* scale, int B, hipStream_t st, bool dx_feeds_gemm = false) {
     TrainState& T = *ctx->train;
     const int C = ctx->cfg.num_cams;
+    if (dgrad_direct(ctx, cl) && T.conv_wd16[li]) {
+        Conv3Args c{};
+        c.x = dys; c.w16 = T.conv_wd16[li]; c.res = res; c.out = dx; c.G = C; c.B = B; c.H = cl.H; c.W = cl.W; c.relu = 0;
+        c.w_scale = ctx->bwd_wscale;
+        c.x_scale_dev = dyn_scale(ctx, dys, cl.cout, C * B * cl.Ho * cl.Wo, cl.cout, st, true);
+        c.mask = mask; c.post_scale = scale;
+        if (dx_feeds_gemm) c.amax_out = amax_pre(ctx, dx, st);
+        return launch_conv3x3_c64(c, st, &ctx->err) == 0 ? 0 : ACTMI_E_LAUNCH;
+    }
     GemmArgs a = G0();
     a.mode = 2; a.A = dys; a.H = cl.H; a.W = cl.W; a.Cin = cl.cin; a.KH = a.KW = cl.k; a.stride = cl.stride; a.pad = cl.pad;
     a.Ho = cl.Ho; a.Wo = cl.Wo; a.img_stride = (int64_t)cl.Ho * cl.Wo * cl.cout;
@@ -478,6 +497,9 @@ int train_create(actmi_ctx* ctx) {
         float *gw, *wd;
         TA(gw, (int64_t)C * cl.cout * cl.K); TA(wd, (int64_t)C * cl.cin * cl.k * cl.k * cl.cout);
         T.conv_gw.push_back(gw); T.conv_wd.push_back(wd);
+        float* wd16 = nullptr;
+        if (dgrad_direct(ctx, cl)) TA(wd16, (int64_t)C * cl.cin * cl.k * cl.k * cl.cout);
+        T.conv_wd16.push_back(wd16);
     }
     TA(T.conv1_gw, (int64_t)C * w0 * 196);
     {
@@ -919,7 +941,9 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
     for (size_t li = 0; li < ctx->convs.size(); ++li) {
         const ConvLayer& cl = ctx->convs[li];
         HIPCHK(hipMemsetAsync(T.conv_gw[li], 0, (size_t)C * cl.cout * cl.K * 4, st));
-        CHK(launch_repack_dgrad_w(cl.w, T.conv_wd[li], C, cl.cout, cl.cin, cl.k * cl.k, st));
+        const bool direct = dgrad_direct(ctx, cl) && T.conv_wd16[li];
+        CHK(launch_repack_dgrad_w(cl.w, T.conv_wd[li], C, cl.cout, cl.cin, cl.k * cl.k, st, direct ? 1 : 0));
+        if (direct) CHK(launch_split16(T.conv_wd[li], T.conv_wd16[li], (int64_t)C * cl.cin * cl.k * cl.k * cl.cout, ctx->bwd_wscale, st));
     }
     HIPCHK(hipMemsetAsync(T.conv1_gw, 0, (size_t)C * w0 * 196 * 4, st));
     float* dz = T.gbuf[1];

@@ -150,6 +150,9 @@ typedef struct actmi_gemm_desc {
     int64_t gRow, gRow2;
     const uint8_t* epi_colkill;
     int64_t gColkill;
+    /* tile shape: 0 = chosen per launch shape, 1 = 128x128, 2 = 128x64, 3 = 64x64 (tuning aid for launches the shape model
+     * misjudges: the K = 64 products of the attention backward are all epilogue) */
+    int32_t tile_hint;
 } actmi_gemm_desc;
 
 /* GEMM / implicit-GEMM convolution on PRE-SPLIT operands (the inference path's form of actmi_gemm_desc with prec f16x3;
