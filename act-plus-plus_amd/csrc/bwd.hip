@@ -114,25 +114,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
 }
 
-// out_a[k] += sum_b part[b][0][k], out_b[k] += sum_b part[b][1][k] in block order (bitwise repeatable; float atomics are not)
-__global__ void reduce_pairs_kernel(const float* __restrict__ part, int nblocks, int D, float* __restrict__ out_a,
-                                    float* __restrict__ out_b) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= 2 * D) return;
-    const int which = k / D, col = k - which * D;
-    float acc = 0.f;
-    for (int b = 0; b < nblocks; ++b) acc += part[((int64_t)b * 2 + which) * D + col];
-    float* o = which ? out_b : out_a;
-    o[col] += acc;
+// Fixed-order sum of ny partial rows: out[n] += sum_y part[y][n].  Block = 64 columns x 4 row lanes; lane l takes the rows
+// y = l (mod 4) in four interleaved chains (16 loads in flight per column), the 16 chain sums are added in a fixed tree:
+// bitwise repeatable (float atomics are not), and ~15x faster than one thread walking all ny rows of its column.
+__device__ __forceinline__ float ordered_colsum(const float* __restrict__ part, int ny, int64_t ld, int col, int rl, float (*s_l)[64]) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int y = rl;
+    for (; y + 12 < ny; y += 16) {
+        a0 += part[(int64_t)y * ld + col];
+        a1 += part[(int64_t)(y + 4) * ld + col];
+        a2 += part[(int64_t)(y + 8) * ld + col];
+        a3 += part[(int64_t)(y + 12) * ld + col];
+    }
+    for (; y < ny; y += 4) a0 += part[(int64_t)y * ld + col];
+    s_l[rl][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    return (s_l[0][threadIdx.x & 63] + s_l[1][threadIdx.x & 63]) + (s_l[2][threadIdx.x & 63] + s_l[3][threadIdx.x & 63]);
 }
 
-// out[n] += sum_y part[y][n] in row-block order
-__global__ void reduce_rows_kernel(const float* __restrict__ part, int ny, int N, float* __restrict__ out) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float acc = 0.f;
-    for (int y = 0; y < ny; ++y) acc += part[(int64_t)y * N + n];
-    out[n] += acc;
+// out_a[k] += sum_b part[b][0][k], out_b[k] += sum_b part[b][1][k]   (LayerNorm backward: block partials of d-gamma / d-beta)
+__global__ __launch_bounds__(256) void reduce_pairs_kernel(const float* __restrict__ part, int nblocks, int D, float* __restrict__ out_a,
+                                                           float* __restrict__ out_b) {
+    __shared__ float s_l[4][64];
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const bool ok = k < 2 * D;
+    const float t = ordered_colsum(part, ok ? nblocks : 0, 2 * (int64_t)D, ok ? k : 0, rl, s_l);
+    if (ok && rl == 0) {
+        const int which = k / D, col = k - which * D;
+        float* o = which ? out_b : out_a;
+        o[col] += t;
+    }
+}
+
+// out[n] += sum_y part[y][n]
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int ny, int N, float* __restrict__ out) {
+    __shared__ float s_l[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const bool ok = n < N;
+    const float t = ordered_colsum(part, ok ? ny : 0, N, ok ? n : 0, rl, s_l);
+    if (ok && rl == 0) out[n] += t;
 }
 
 // ---------------------------------------------------------------------------------------------- max-pool bwd
@@ -199,6 +219,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ s
     for (int m = m0; m < m1; ++m) acc += src[(int64_t)m * ld + n];
     if (part) part[(int64_t)blockIdx.y * N + n] = acc;
     else atomicAdd(&out[n], acc);
+}
+
+// the same with four columns per thread (N, ld multiples of 4): block = 64 column groups x 4 row lanes over rows_per_block rows,
+// four loads in flight per lane, lanes combined in a fixed order; always writes a partial per row block
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const f32x4* __restrict__ src, int64_t ld4, int M, int N4, int rows_per_block,
+                                                         f32x4* __restrict__ part) {
+    __shared__ f32x4 s_l[4][64];
+    const int cg = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const bool ok = cg < N4;
+    const int m0 = blockIdx.y * rows_per_block;
+    const int m1 = (m0 + rows_per_block < M) ? m0 + rows_per_block : M;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a0 = z, a1 = z, a2 = z, a3 = z;
+    if (ok) {
+        const f32x4* p = src + cg;
+        int m = m0 + rl;
+        for (; m + 12 < m1; m += 16) {
+            a0 += p[(int64_t)m * ld4];
+            a1 += p[(int64_t)(m + 4) * ld4];
+            a2 += p[(int64_t)(m + 8) * ld4];
+            a3 += p[(int64_t)(m + 12) * ld4];
+        }
+        for (; m < m1; m += 4) a0 += p[(int64_t)m * ld4];
+    }
+    s_l[rl][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ok && rl == 0)
+        part[(int64_t)blockIdx.y * N4 + cg] = (s_l[0][threadIdx.x & 63] + s_l[1][threadIdx.x & 63]) +
+                                              (s_l[2][threadIdx.x & 63] + s_l[3][threadIdx.x & 63]);
 }
 
 // dst[r][d] (+)= sum_b src[b*bs + r*ld + d]
@@ -558,7 +607,7 @@ int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* 
         default: ACTMI_LNB(MAXV); break;
     }
 #undef ACTMI_LNB
-    if (part) hipLaunchKernelGGL(reduce_pairs_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, part, blocks, D, dw, db);
+    if (part) hipLaunchKernelGGL(reduce_pairs_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, st, part, blocks, D, dw, db);
     prof_end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -625,12 +674,27 @@ int launch_maxpool_bwd(const float* x, const float* dy, float* dx, int nimg, int
 
 int launch_colsum(const float* src, int64_t ld, float* out, int M, int N, hipStream_t st, float* ws, int64_t ws_floats) {
     if (M <= 0 || N <= 0) return 0;
+    prof_begin("colsum_kernel", 0.0, 4.0 * M * N, st);
+    const bool vec = (N & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)src & 15) == 0 && ws && ((uintptr_t)ws & 15) == 0;
     int rpb = 256;
+    if (vec) {
+        // row blocks sized for ~1000 workgroups in all; one partial row per block, then the ordered sum
+        const int gx = (N / 4 + 63) / 64;
+        while (rpb < 4096 && (int64_t)gx * ((M + rpb - 1) / rpb) > 1024) rpb *= 2;
+        const int gy = (M + rpb - 1) / rpb;
+        if ((int64_t)gy * N <= ws_floats) {
+            hipLaunchKernelGGL(colsum_vec_kernel, dim3(gx, gy), dim3(256), 0, st, reinterpret_cast<const f32x4*>(src), ld / 4, M, N / 4,
+                               rpb, reinterpret_cast<f32x4*>(ws));
+            hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 63) / 64), dim3(256), 0, st, ws, gy, N, out);
+            prof_end(st);
+            return hipGetLastError() == hipSuccess ? 0 : -3;
+        }
+        rpb = 256;
+    }
     dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
     float* part = (ws && grid.y > 1 && (int64_t)grid.y * N <= ws_floats) ? ws : nullptr;      // one row block: already ordered
-    prof_begin("colsum_kernel", 0.0, 4.0 * M * N, st);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, src, ld, out, M, N, rpb, part);
-    if (part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, (int)grid.y, N, out);
+    if (part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 63) / 64), dim3(256), 0, st, part, (int)grid.y, N, out);
     prof_end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
