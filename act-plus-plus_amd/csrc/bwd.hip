@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ dy, const float* __restrict__ dx_add,
                                                      float* __restrict__ dx, float* __restrict__ dw,
                                                      float* __restrict__ db, int M, int D, float eps,
-                                                     float* __restrict__ part) {
+                                                     float* __restrict__ part, unsigned* __restrict__ dx_amax) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nw = gridDim.x * 4;
@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
     for (int i = 0; i < NV; ++i) { aw[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = aw[i]; }
     const float invD = 1.f / (float)D;
+    unsigned amx = 0;                  // bits of max |dx| (dx_amax: operand scale of the products that read dx next)
     for (int row = wid; row < M; row += nw) {
         const f32x4* xr = reinterpret_cast<const f32x4*>(x + (int64_t)row * D);
         const f32x4* gr = reinterpret_cast<const f32x4*>(dy + (int64_t)row * D);
@@ -73,8 +74,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                 f32x4 o = (g[i] - m1 - v[i] * m2) * rstd;
                 if (ar) o += ar[c];
                 dr[c] = o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) amx = max(amx, __float_as_uint(o[e]) & 0x7fffffffu);
             }
         }
+    }
+    if (dx_amax) {
+        for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
+        if (lane == 0 && amx) amax_commit(dx_amax, amx);
     }
     // block-level reduction of the 4 waves' partials through LDS, then ONE atomic per column per block
     // (4096 waves adding to the same 2*D addresses was 15x slower than the row pass itself)
@@ -587,7 +594,7 @@ int launch_attn_ds_drop(const float* P, float* dP, const float* delta, float sca
 }
 
 int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* dx_add, float* dx, float* dw, float* db,
-                  int M, int D, float eps, hipStream_t st, float* ws, int64_t ws_floats) {
+                  int M, int D, float eps, hipStream_t st, float* ws, int64_t ws_floats, unsigned* dx_amax) {
     if ((D & 3) || D > 64 * 4 * MAXV) return -2;
     if (M <= 0) return 0;
     // persistent workgroups (each adds its dw/db partials once): 4 per CU -- with one wave per SIMD (256 workgroups) the
@@ -598,7 +605,7 @@ int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* 
     float* part = (ws && (int64_t)blocks * 2 * D <= ws_floats) ? ws : nullptr;
     prof_begin("ln_bwd_kernel", 0.0, 4.0 * M * D * 3.0, st);
     const int nv = (D / 4 + 63) / 64;
-#define ACTMI_LNB(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(blocks), dim3(256), 0, st, x, w, dy, dx_add, dx, dw, db, M, D, eps, part)
+#define ACTMI_LNB(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(blocks), dim3(256), 0, st, x, w, dy, dx_add, dx, dw, db, M, D, eps, part, dx_amax)
     switch (nv) {
         case 1: ACTMI_LNB(1); break;
         case 2: ACTMI_LNB(2); break;

@@ -148,7 +148,7 @@ void prof_end(hipStream_t st);
 // ---- backward-pass kernels (bwd.hip, misc.hip) ---------------------------------------------------------
 // ws (optional): scratch for the deterministic form -- per-block dw / db partials summed in block order instead of float atomics
 int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* dx_add, float* dx, float* dw, float* db,
-                  int M, int D, float eps, hipStream_t st, float* ws = nullptr, int64_t ws_floats = 0);
+                  int M, int D, float eps, hipStream_t st, float* ws = nullptr, int64_t ws_floats = 0, unsigned* dx_amax = nullptr);
 int launch_maxpool_bwd(const float* x, const float* dy, float* dx, int nimg, int H, int W, int C, int Ho, int Wo,
                        hipStream_t st);
 int launch_colsum(const float* src, int64_t ld, float* out, int M, int N, hipStream_t st, float* ws = nullptr, int64_t ws_floats = 0);

@@ -91,8 +91,8 @@ int tgemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
 
 // LayerNorm backward / column sums with their partials summed in a fixed order (TrainState::det_ws)
 int ln_bwd_d(actmi_ctx* ctx, const float* x, const float* w, const float* dy, const float* dx_add, float* dx, float* dw, float* db,
-             int M, int D, float eps, hipStream_t st) {
-    return launch_ln_bwd(x, w, dy, dx_add, dx, dw, db, M, D, eps, st, ctx->train->det_ws, ctx->train->det_ws_floats);
+             int M, int D, float eps, hipStream_t st, unsigned* dx_amax = nullptr) {
+    return launch_ln_bwd(x, w, dy, dx_add, dx, dw, db, M, D, eps, st, ctx->train->det_ws, ctx->train->det_ws_floats, dx_amax);
 }
 int colsum_d(actmi_ctx* ctx, const float* src, int64_t ld, float* out, int M, int N, hipStream_t st) {
     return launch_colsum(src, ld, out, M, N, st, ctx->train->det_ws, ctx->train->det_ws_floats);
@@ -163,12 +163,15 @@ int lin_fwd(actmi_ctx* ctx, const float* x, int64_t ldx, int M, int K, const flo
 
 // dx[M][K] = dy[M][N] W[N][K] (+res) (masked by mask>0)
 int lin_dgrad(actmi_ctx* ctx, const float* dy, int64_t lddy, int M, int N, const float* W, int K, float* dx, int64_t lddx,
-              const float* res, const float* mask, hipStream_t st, float alpha = 1.f) {
+              const float* res, const float* mask, hipStream_t st, float alpha = 1.f, bool dx_feeds_gemm = false) {
     GemmArgs a = G0();
     a.A = dy; a.lda = lddy; a.M = M; a.K = N; a.N = K; a.Bw = W; a.ldb = K; a.tb = 1; a.C = dx; a.ldc = lddx;
     a.res = res; a.ldres = lddx; a.mask = mask; a.ldmask = lddx; a.alpha = alpha;
     a.b_scale = ctx->bwd_wscale;
     a.a_scale_dev = dyn_scale(ctx, dy, lddy, M, N, st, true);
+    // dx is the dY operand of the next data / weight gradient pair (same pointer, ld, M and K columns): its maximum is taken
+    // in this product's epilogue
+    if (dx_feeds_gemm && lddx == K) a.amax_out = amax_pre(ctx, dx, st);
     return tgemm(ctx, a, st);
 }
 
@@ -329,20 +332,22 @@ int enc_bwd(actmi_ctx* ctx, const EncW& w, const EncSave& s, const float* dOut, 
     const bool drop = dr.p > 0.f;
     const float inv_keep = drop ? 1.f / (1.f - dr.p) : 1.f;
     // norm2:  Y2 = X1 + drop3(linear2(Hb))
-    CHK(ln_bwd_d(ctx, s.Y2, w.n2w, dOut, nullptr, gA, Gp(w.n2w), Gp(w.n2b), M, D, 1e-5f, st));             // gA = dY2
+    CHK(ln_bwd_d(ctx, s.Y2, w.n2w, dOut, nullptr, gA, Gp(w.n2w), Gp(w.n2b), M, D, 1e-5f, st,
+                 drop ? nullptr : amax_pre(ctx, gA, st)));                                                   // gA = dY2
     const float* dz2 = gA;
     if (drop) { CHK(launch_dropout_bwd(gA, gC, dr.s(3), dr.p, (int64_t)M * D, st)); dz2 = gC; }
     // linear2 / dropout / relu / linear1:  Hb = drop2(relu(linear1(X1))); dropped or negative entries are 0 in Hb
-    CHK(lin_dgrad(ctx, dz2, D, M, D, w.l2w, F, gH, F, nullptr, s.Hb, st, inv_keep));                         // gH = dHpre
+    CHK(lin_dgrad(ctx, dz2, D, M, D, w.l2w, F, gH, F, nullptr, s.Hb, st, inv_keep, true));                   // gH = dHpre
     CHK(lin_wgrad(ctx, dz2, D, M, D, s.Hb, F, F, nullptr, 0, Gp(w.l2w), Gp(w.l2b), st));
     CHK(lin_dgrad(ctx, gH, F, M, F, w.l1w, D, gC, D, gA, nullptr, st));                                      // gC = dX1
     CHK(lin_wgrad(ctx, gH, F, M, F, s.X1, D, D, nullptr, 0, Gp(w.l1w), Gp(w.l1b), st));
     // norm1:  Y1 = x_in + drop1(out_proj(ATT))
-    CHK(ln_bwd_d(ctx, s.Y1, w.n1w, gC, nullptr, gA, Gp(w.n1w), Gp(w.n1b), M, D, 1e-5f, st));               // gA = dY1
+    CHK(ln_bwd_d(ctx, s.Y1, w.n1w, gC, nullptr, gA, Gp(w.n1w), Gp(w.n1b), M, D, 1e-5f, st,
+                 drop ? nullptr : amax_pre(ctx, gA, st)));                                                   // gA = dY1
     const float* dz1 = gA;
     if (drop) { CHK(launch_dropout_bwd(gA, gC, dr.s(1), dr.p, (int64_t)M * D, st)); dz1 = gC; }
     float* dATT = gH;                                                                                        // [M][D] view
-    CHK(lin_dgrad(ctx, dz1, D, M, D, w.attn.out_w, D, dATT, D, nullptr, nullptr, st));
+    CHK(lin_dgrad(ctx, dz1, D, M, D, w.attn.out_w, D, dATT, D, nullptr, nullptr, st, 1.f, true));            // dATT = dO of the attention
     CHK(lin_wgrad(ctx, dz1, D, M, D, s.ATT, D, D, nullptr, 0, Gp(w.attn.out_w), Gp(w.attn.out_b), st));
     // attention
     AttnBwd t;
