@@ -203,8 +203,11 @@ class ACTEngine:
             with_ensemble.reset()               # the capture itself does not execute, but keep the state explicit
 
         def replay(qpos, image):
-            s_qpos.copy_(qpos, non_blocking=True)
-            s_img.copy_(image, non_blocking=True)
+            # a caller that owns the step's inputs writes them straight into replay.static (H2D copies land there): no copy
+            if qpos.data_ptr() != s_qpos.data_ptr():
+                s_qpos.copy_(qpos, non_blocking=True)
+            if image.data_ptr() != s_img.data_ptr():
+                s_img.copy_(image, non_blocking=True)
             graph.replay()
             return (s_out, ens_out) if with_ensemble is not None else s_out
 

@@ -46,6 +46,7 @@ class GemmDesc(C.Structure):
         ("split_stride", C.c_int64), ("amax_out", C.c_void_p),
         ("epi", C.c_int32), ("epi_scale", C.c_float), ("epi_row", C.c_void_p), ("gRow", C.c_int64), ("gRow2", C.c_int64),
         ("epi_colkill", C.c_void_p), ("gColkill", C.c_int64), ("tile_hint", C.c_int32),
+        ("finite_flag", C.c_void_p), ("finite_bit", C.c_uint32),
     ]
 
 

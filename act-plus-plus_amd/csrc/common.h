@@ -129,7 +129,8 @@ int launch_attention(const AttnArgs& a, hipStream_t st, std::string* err);
 
 // ---- small kernels (misc.hip) --------------------------------------------------------------------
 int launch_small_linear(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
-                        int M, int N, int K, hipStream_t st);
+                        int M, int N, int K, hipStream_t st, float* fill_dst = nullptr, const float* fill_src = nullptr,
+                        int64_t fill_src_bs = 0);
 int launch_fill_rows(float* dst, int64_t ld, int64_t batch_stride, const float* src, int64_t src_bs, int B, int D,
                      hipStream_t st);
 int launch_repack_conv_w(const float* w_oihw, float* w_ohwi, int G, int O, int I, int KH, int KW, int64_t g_in,

@@ -137,6 +137,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
         stamp[1] = ((uint64_t)xcc << 32) | hw;
     }
     unsigned* const amax_out = UNMASKED ? nullptr : p.amax_out;
+    unsigned* const fflag = UNMASKED ? nullptr : p.finite_flag;
+    const bool track = amax_out != nullptr || fflag != nullptr;
     const unsigned amax_seen = amax_out ? __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     const int nk_total = (p.K + BK - 1) / BK;
     const int tps = (nk_total + splitk - 1) / splitk;
@@ -722,8 +724,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                         (int64_t)p.M * p.ldc < (int64_t)1 << 31 && (!res || (int64_t)p.M * p.ldres < (int64_t)1 << 31);
     unsigned amx = 0;                  // bits of max |stored value| (p.amax_out)
     auto amax_flush = [&]() {
-        if (!amax_out) return;
+        if (!track) return;
         for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
+        if (fflag && lane == 0 && amx >= 0x7f800000u) atomicOr(fflag, p.finite_bit);      // inf / NaN bits order above every finite value
+        if (!amax_out) return;
         // amax_seen was read when the block started (a lower bound of the running maximum: it only filters): no load
         // latency at the tail of every tile
         if (lane == 0 && amx > amax_seen) atomicMax(amax_out, amx);
@@ -788,7 +792,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                             for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
                         }
                         *reinterpret_cast<f32x4*>(C + (uint32_t)(m * (int)p.ldc + ncol)) = v;
-                        if (amax_out) {
+                        if (track) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) amx = max(amx, __float_as_uint(v[e]) & 0x7fffffffu);
                         }
@@ -831,7 +835,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                     if (gelu) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
                     if (nok && m < p.M) {
                         C[(uint32_t)(m * (int)p.ldc + n)] = v;
-                        if (amax_out) amx = max(amx, __float_as_uint(v) & 0x7fffffffu);
+                        if (track) amx = max(amx, __float_as_uint(v) & 0x7fffffffu);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -886,7 +890,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (splitk > 1 && p.split_stride == 0) atomicAdd(&C[o], v);
                     else C[o] = v;
-                    if (amax_out) amx = max(amx, __float_as_uint(v) & 0x7fffffffu);
+                    if (track) amx = max(amx, __float_as_uint(v) & 0x7fffffffu);
                     if (C2) C2[o] = v * sc2;
                 }
             }
@@ -941,7 +945,7 @@ int launch_cfg_b(const GemmArgs& a, hipStream_t st) {
     if constexpr (HOT) {
         const bool one_a = (a.a_scale == 0.f || a.a_scale == 1.f) && !a.a_scale_dev;
         const bool one_b = BSPLIT || ((a.b_scale == 0.f || a.b_scale == 1.f) && !a.b_scale_dev);
-        if ((a.K % BK) == 0 && one_a && one_b && a.epi == 0 && !a.amax_out) return launch_cfg_u<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, 1>(a, st);
+        if ((a.K % BK) == 0 && one_a && one_b && a.epi == 0 && !a.amax_out && !a.finite_flag) return launch_cfg_u<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, 1>(a, st);
     }
     return launch_cfg_u<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, 0>(a, st);
 }

@@ -8,7 +8,7 @@ namespace {
 // (input_proj_robot_state / encoder_joint_proj / encoder_action_proj / latent_out_proj; detr_vae.py:63,81-82,97)
 __global__ void small_linear_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
                                     const float* __restrict__ b, float* __restrict__ y, int64_t ldy, int M, int N,
-                                    int K) {
+                                    int K, float* __restrict__ fill_dst, const float* __restrict__ fill_src, int64_t fill_src_bs) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)M * N) return;
     const int m = (int)(idx / N), n = (int)(idx - (int64_t)m * N);
@@ -17,6 +17,9 @@ __global__ void small_linear_kernel(const float* __restrict__ x, int64_t ldx, co
     float acc = 0.f;
     for (int k = 0; k < K; ++k) acc = fmaf(xr[k], wr[k], acc);
     y[(int64_t)m * ldy + n] = acc + (b ? b[n] : 0.f);
+    // optional companion row (same M x N index space): fill_dst[m][n] = fill_src[m * fill_src_bs + n] -- the latent token
+    // next to the proprio token of the encoder input (detr_vae.py:158-159, 213), one launch instead of two
+    if (fill_dst) fill_dst[(int64_t)m * ldy + n] = fill_src[(int64_t)m * fill_src_bs + n];
 }
 
 __global__ void fill_rows_kernel(float* __restrict__ dst, int64_t batch_stride, const float* __restrict__ src,
@@ -550,11 +553,11 @@ int launch_build_rowmap(int* map, int B, int C, int fh, int fw, int N, hipStream
 }
 
 int launch_small_linear(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int M,
-                        int N, int K, hipStream_t st) {
+                        int N, int K, hipStream_t st, float* fill_dst, const float* fill_src, int64_t fill_src_bs) {
     const int64_t total = (int64_t)M * N;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(small_linear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, ldx, w, b, y,
-                       ldy, M, N, K);
+                       ldy, M, N, K, fill_dst, fill_src, fill_src_bs);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

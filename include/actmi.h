@@ -153,6 +153,10 @@ typedef struct actmi_gemm_desc {
     /* tile shape: 0 = chosen per launch shape, 1 = 128x128, 2 = 128x64, 3 = 64x64 (tuning aid for launches the shape model
      * misjudges: the K = 64 products of the attention backward are all epilogue) */
     int32_t tile_hint;
+    /* optional: OR finite_bit into *finite_flag when any value this launch stores is NaN or infinite (the handle's output
+     * guard rides on the last product of the forward instead of a pass of its own) */
+    uint32_t* finite_flag;
+    uint32_t finite_bit;
 } actmi_gemm_desc;
 
 /* GEMM / implicit-GEMM convolution on PRE-SPLIT operands (the inference path's form of actmi_gemm_desc with prec f16x3;
