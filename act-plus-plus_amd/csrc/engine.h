@@ -117,6 +117,12 @@ struct actmi_ctx {
     hipStream_t side_stream = nullptr; // downsample branch of the ResNet blocks (engine_backbone)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool ds_fork = true;
+    // two camera halves of the ResNet trunk as two parallel branches (second stream): the tail of one half's launch is
+    // filled by the other half's next launch (default on, ACTMI_CAM_PIPE=0 disables; engine_backbone)
+    hipStream_t pipe_stream = nullptr;
+    hipEvent_t ev_pfork = nullptr, ev_pjoin = nullptr;
+    bool cam_pipe = false;
+    int policy_mult = 1;               // split-K policy counts the tiles of the WHOLE camera set while a half is being launched
     bool conv_direct = false;          // layer2-4 stride-1 3x3 convolutions on the direct kernel (conv3g.hip): measured slower, opt-in
     int conv_direct_min_images = 8;    // below this many images (cameras x batch) its grid is too small: implicit GEMM + split-K
     int64_t ptotal = 0;
@@ -147,7 +153,7 @@ struct actmi_ctx {
 
 int engine_create(const actmi_config* cfg, actmi_ctx** out);
 // forward GEMMs of a handle go through here: applies the handle's precision and swaps in pre-split weights
-int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st);
+int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half = -1);
 int engine_destroy(actmi_ctx* ctx);
 const char* engine_create_error();
 int engine_finalize(actmi_ctx* ctx, hipStream_t st);

@@ -153,8 +153,11 @@ int dev_alloc(actmi_ctx* ctx, float** p, int64_t nfloats) {
 
 }  // namespace
 
-int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
+int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half) {
     a.prec = ctx->gemm_prec;
+    // ws_half 0 / 1: this launch belongs to one of two concurrent branches, each with its own half of the slice workspace
+    float* const ws = ctx->splitk_ws ? ctx->splitk_ws + (ws_half > 0 ? ctx->splitk_ws_floats / 2 : 0) : nullptr;
+    const int64_t ws_floats = ws_half >= 0 ? ctx->splitk_ws_floats / 2 : ctx->splitk_ws_floats;
     if (ctx->gemm_prec == ACTMI_PREC_F16X3 && a.tb == 0) {
         // B is a weight matrix: use its pre-split image (same offsets) where one exists
         if (a.Bw >= ctx->pbase && a.Bw < ctx->pbase + ctx->ptotal) {
@@ -163,7 +166,9 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
             a.b_split = 1;
         } else {
             for (const ConvLayer& cl : ctx->convs)
-                if (a.Bw == cl.w) { a.Bw = cl.w16; a.b_split = 1; a.b_scale = cl.w16_scale; break; }
+                if (a.Bw >= cl.w && a.Bw < cl.w + (int64_t)ctx->cfg.num_cams * cl.cout * cl.K) {     // (a camera's slice of it)
+                    a.Bw = cl.w16 + (a.Bw - cl.w); a.b_split = 1; a.b_scale = cl.w16_scale; break;
+                }
         }
     }
     // Small grids (B = 1-4 rollouts: layer3/4 convolutions, the K = 3200 FFN products): a launch of a few hundred tiles
@@ -174,7 +179,7 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
     if (ctx->fwd_splitk && ctx->splitk_ws && a.splitk <= 1 && a.tb == 0 && a.ta == 0 && (a.mode == 0 || a.mode == 1) &&
         !a.rowmap && !a.C2 && !a.mask && a.drop_p == 0.f && a.res_mod == 0 && a.groups_inner == 0 && !a.stamps) {
         const int groups = a.groups > 0 ? a.groups : 1;
-        const int64_t tiles = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64) * groups;
+        const int64_t tiles = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64) * groups * (ws_half >= 0 ? ctx->policy_mult : 1);
         const int nk = (a.K + 31) / 32;
         int S = tiles < ctx->sk_maxtiles ? (int)((ctx->sk_target + tiles - 1) / tiles) : 1;
         // B = 8: the 304-workgroup launches with a very long contraction (layer4's K = 4608 convolutions: 217 us unsplit,
@@ -185,11 +190,11 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
         if (S > nk / ctx->sk_minnk) S = nk / ctx->sk_minnk;
         while (S >= 2 && (S - 1) * ((nk + S - 1) / S) >= nk) --S;              // every split must own a K tile
         const int64_t slice = (int64_t)a.M * a.N;
-        if (S >= 2 && slice * groups * S <= ctx->splitk_ws_floats && (a.N & 3) == 0) {
+        if (S >= 2 && slice * groups * S <= ws_floats && (a.N & 3) == 0) {
             GemmArgs p = a;
             p.scale = p.bias = p.res = nullptr;
             p.relu = 0;
-            p.C = ctx->splitk_ws;
+            p.C = ws;
             p.ldc = a.N;
             p.gC = slice * S;
             p.splitk = S;
@@ -197,7 +202,7 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
             int rc = launch_gemm(p, st, &ctx->err);
             if (rc) return rc;
             SplitCombineArgs c{};
-            c.part = ctx->splitk_ws; c.nsplit = S; c.split_stride = slice; c.gP = slice * S; c.ldp = a.N;
+            c.part = ws; c.nsplit = S; c.split_stride = slice; c.gP = slice * S; c.ldp = a.N;
             c.scale = a.scale; c.bias = a.bias; c.gSB = a.gSB;
             c.res = a.res; c.ldres = a.ldres; c.gRes = a.gRes;
             c.relu = a.relu;
@@ -510,6 +515,14 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
             ctx->err = "cannot create the side stream";
             return fail(ACTMI_E_LAUNCH);
         }
+        const char* e5 = getenv("ACTMI_CAM_PIPE");
+        ctx->cam_pipe = !(e5 && e5[0] == '0');             // default on; ACTMI_CAM_PIPE=0: one branch (every launch spans all cameras)
+        if (ctx->cam_pipe && (hipStreamCreateWithFlags(&ctx->pipe_stream, hipStreamNonBlocking) != hipSuccess ||
+                              hipEventCreateWithFlags(&ctx->ev_pfork, hipEventDisableTiming) != hipSuccess ||
+                              hipEventCreateWithFlags(&ctx->ev_pjoin, hipEventDisableTiming) != hipSuccess)) {
+            ctx->err = "cannot create the camera-pipeline stream";
+            return fail(ACTMI_E_LAUNCH);
+        }
     }
     ctx->finalized = false;
     if (g.enable_training && (rc = train_create(ctx))) return fail(rc);
@@ -523,6 +536,9 @@ int engine_destroy(actmi_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->ev_pfork) (void)hipEventDestroy(ctx->ev_pfork);
+    if (ctx->ev_pjoin) (void)hipEventDestroy(ctx->ev_pjoin);
+    if (ctx->pipe_stream) (void)hipStreamDestroy(ctx->pipe_stream);
     if (ctx->train && ctx->train->ev_phase1) (void)hipEventDestroy(ctx->train->ev_phase1);
     delete ctx->train;
     delete ctx;
@@ -651,19 +667,24 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
         CHK(launch_conv1(c1, st, &ctx->err));
         CHK(launch_maxpool(ctx->act1, ctx->buf[0], C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
     }
-    float* cur = ctx->buf[0];
-    float* s1 = ctx->buf[1];
-    float* s2 = ctx->buf[2];
     ctx->dbg.clear();
     ctx->dbg["conv1"] = {ctx->act1, (int64_t)C * B * ctx->H1 * ctx->W1 * w0};
-    ctx->dbg["maxpool"] = {cur, (int64_t)C * B * ctx->H2 * ctx->W2 * w0};
+    ctx->dbg["maxpool"] = {ctx->buf[0], (int64_t)C * B * ctx->H2 * ctx->W2 * w0};
     if (ctx->stop_stage == "conv1" || ctx->stop_stage == "maxpool") return 1;
-    auto run_conv_on = [&](const ConvLayer& cl, const float* in, float* out, const float* res, int relu, hipStream_t cs) -> int {
+    // one convolution of the trunk for the cameras [c0, c0 + nc) (feature maps and weights are camera-major, so a camera range
+    // is a pointer offset + a group count); half >= 0: one of two concurrent branches (own half of the slice workspace)
+    auto run_conv_on = [&](const ConvLayer& cl, const float* in, float* out, const float* res, int relu, hipStream_t cs, int c0,
+                           int nc, int half) -> int {
+        // (in / out / res already point at the range's first camera: run_layers)
+        const int64_t in_cam = (int64_t)B * cl.H * cl.W * cl.cin;
+        const int64_t w_cam = (int64_t)cl.cout * cl.K;
+        const float* scale = cl.scale + (int64_t)c0 * cl.cout;
+        const float* bias = cl.bias + (int64_t)c0 * cl.cout;
         if (ctx->gemm_prec == ACTMI_PREC_F16X3 && cl.k == 3 && cl.stride == 1 && cl.pad == 1 && cl.cin == 64 && cl.cout == 64) {
             // layer1: direct convolution over an LDS-resident patch (the im2col GEMM is L2-traffic bound at 64 channels)
             Conv3Args c3;
-            c3.x = in; c3.w16 = cl.w16; c3.scale = cl.scale; c3.bias = cl.bias; c3.res = res; c3.out = out;
-            c3.G = C; c3.B = B; c3.H = cl.H; c3.W = cl.W; c3.relu = relu; c3.w_scale = cl.w16_scale;
+            c3.x = in; c3.w16 = cl.w16 + c0 * w_cam; c3.scale = scale; c3.bias = bias; c3.res = res; c3.out = out;
+            c3.G = nc; c3.B = B; c3.H = cl.H; c3.W = cl.W; c3.relu = relu; c3.w_scale = cl.w16_scale;
             return launch_conv3x3_c64(c3, cs, &ctx->err);
         }
         if (ctx->gemm_prec == ACTMI_PREC_F16X3 && ctx->conv_direct && cl.k == 3 && cl.stride == 1 && cl.pad == 1 &&
@@ -671,8 +692,8 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
             // layer2-4 stride-1 convolutions: the same direct scheme per 64-channel chunk (conv3g.hip) -- a third fewer
             // operand bytes per MFMA than the implicit GEMM at its 128x128 tile
             Conv3gArgs cg;
-            cg.x = in; cg.w16 = cl.w16; cg.scale = cl.scale; cg.bias = cl.bias; cg.res = res; cg.out = out;
-            cg.G = C; cg.B = B; cg.H = cl.H; cg.W = cl.W; cg.Cin = cl.cin; cg.Cout = cl.cout; cg.relu = relu; cg.w_scale = cl.w16_scale;
+            cg.x = in; cg.w16 = cl.w16 + c0 * w_cam; cg.scale = scale; cg.bias = bias; cg.res = res; cg.out = out;
+            cg.G = nc; cg.B = B; cg.H = cl.H; cg.W = cl.W; cg.Cin = cl.cin; cg.Cout = cl.cout; cg.relu = relu; cg.w_scale = cl.w16_scale;
             return launch_conv3x3_direct(cg, cs, &ctx->err);
         }
         GemmArgs a;
@@ -681,61 +702,90 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
         a.A = in; a.H = cl.H; a.W = cl.W; a.Cin = cl.cin; a.KH = a.KW = cl.k; a.stride = cl.stride; a.pad = cl.pad;
         a.Ho = cl.Ho; a.Wo = cl.Wo; a.img_stride = (int64_t)cl.H * cl.W * cl.cin;
         a.M = B * cl.Ho * cl.Wo; a.N = cl.cout; a.K = cl.K;
-        a.Bw = cl.w; a.ldb = cl.K; a.scale = cl.scale; a.bias = cl.bias; a.res = res; a.ldres = cl.cout; a.relu = relu;
+        a.Bw = cl.w + c0 * w_cam; a.ldb = cl.K; a.scale = scale; a.bias = bias; a.res = res; a.ldres = cl.cout; a.relu = relu;
         a.C = out; a.ldc = cl.cout;
-        a.groups = C;
-        a.gA = (int64_t)B * cl.H * cl.W * cl.cin; a.gB = (int64_t)cl.cout * cl.K; a.gSB = cl.cout;
+        a.groups = nc;
+        a.gA = in_cam; a.gB = w_cam; a.gSB = cl.cout;
         a.gC = (int64_t)a.M * cl.cout; a.gRes = a.gC;
-        return ctx_gemm(ctx, a, cs);
-    };
-    auto run_conv = [&](const ConvLayer& cl, const float* in, float* out, const float* res, int relu) -> int {
-        return run_conv_on(cl, in, out, res, relu, st);
+        return ctx_gemm(ctx, a, cs, half);
     };
     // the side branch needs the split-K workspace for itself: only taken when the main stream's launches do not split
-    const bool fork_ds = ctx->side_stream != nullptr && ctx->ds_fork;
-    size_t ci = 0;
-    for (int li = 1; li <= 4; ++li) {
-        for (int bi = 0; bi < 2; ++bi) {
-            const ConvLayer& k1 = ctx->convs[ci++];
-            const ConvLayer& k2 = ctx->convs[ci++];
-            const bool has_ds = (bi == 0 && li > 1);
-            if (has_ds) {
-                const ConvLayer& ds = ctx->convs[ci++];
-                if (fork_ds) {
-                    // the 1x1 / stride-2 downsample (23-50 us, HBM bound, few workgroups) only needs the block input: it
-                    // runs on a second stream beside the block's first 3x3 convolution (fork / join through events: in a
-                    // captured graph these are two parallel branches) and fills CUs that launch leaves idle
-                    HIPCHK(hipEventRecord(ctx->ev_fork, st));
-                    HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
-                    CHK(run_conv_on(ds, cur, s2, nullptr, 0, ctx->side_stream));
-                    HIPCHK(hipEventRecord(ctx->ev_join, ctx->side_stream));
-                    CHK(run_conv(k1, cur, s1, nullptr, 1));
-                    HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    // (not while the per-launch profiler brackets launches with events, nor for the debug early-outs)
+    const bool pipe = ctx->cam_pipe && ctx->pipe_stream && C >= 2 && !prof_enabled() && ctx->stop_stage.empty();
+    const bool fork_ds = ctx->side_stream != nullptr && ctx->ds_fork && !pipe;
+    float* final_cur = nullptr;
+    // layer1 .. layer4 for the cameras [c0, c0 + nc) on stream ls
+    auto run_layers = [&](int c0, int nc, hipStream_t ls, int half) -> int {
+        // the range's maps live at the offset of its first camera in the POOLED map (the largest per-camera block): every
+        // later map of the range fits behind it without reaching the next range's block, whatever layer the other branch is in
+        const int64_t hb = (int64_t)c0 * B * ctx->H2 * ctx->W2 * w0;
+        float *cur = ctx->buf[0] + hb, *s1 = ctx->buf[1] + hb, *s2 = ctx->buf[2] + hb;
+        auto run_conv = [&](const ConvLayer& cl, const float* in, float* out, const float* res, int relu) -> int {
+            return run_conv_on(cl, in, out, res, relu, ls, c0, nc, half);
+        };
+        size_t ci = 0;
+        for (int li = 1; li <= 4; ++li) {
+            for (int bi = 0; bi < 2; ++bi) {
+                const ConvLayer& k1 = ctx->convs[ci++];
+                const ConvLayer& k2 = ctx->convs[ci++];
+                const bool has_ds = (bi == 0 && li > 1);
+                if (has_ds) {
+                    const ConvLayer& ds = ctx->convs[ci++];
+                    if (fork_ds) {
+                        // the 1x1 / stride-2 downsample (23-50 us, HBM bound, few workgroups) only needs the block input: it
+                        // runs on a second stream beside the block's first 3x3 convolution (fork / join through events: in a
+                        // captured graph these are two parallel branches) and fills CUs that launch leaves idle
+                        HIPCHK(hipEventRecord(ctx->ev_fork, ls));
+                        HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+                        CHK(run_conv_on(ds, cur, s2, nullptr, 0, ctx->side_stream, c0, nc, half));
+                        HIPCHK(hipEventRecord(ctx->ev_join, ctx->side_stream));
+                        CHK(run_conv(k1, cur, s1, nullptr, 1));
+                        HIPCHK(hipStreamWaitEvent(ls, ctx->ev_join, 0));
+                    } else {
+                        CHK(run_conv(k1, cur, s1, nullptr, 1));
+                        CHK(run_conv(ds, cur, s2, nullptr, 0));
+                    }
+                    CHK(run_conv(k2, s1, cur, s2, 1));       // x is dead: reuse its buffer for the block output
                 } else {
                     CHK(run_conv(k1, cur, s1, nullptr, 1));
-                    CHK(run_conv(ds, cur, s2, nullptr, 0));
+                    CHK(run_conv(k2, s1, s2, cur, 1));
+                    std::swap(cur, s2);
                 }
-                CHK(run_conv(k2, s1, cur, s2, 1));       // x is dead: reuse its buffer for the block output
-            } else {
-                CHK(run_conv(k1, cur, s1, nullptr, 1));
-                CHK(run_conv(k2, s1, s2, cur, 1));
-                std::swap(cur, s2);
-            }
-            if (bi == 1) {
-                const std::string nm = "layer" + std::to_string(li);
-                ctx->dbg[nm] = {cur, (int64_t)C * B * k2.Ho * k2.Wo * k2.cout};
-                if (ctx->stop_stage == nm) return 1;    // debug early-out: buffers rotate, views alias
+                if (bi == 1 && c0 == 0) {
+                    const std::string nm = "layer" + std::to_string(li);
+                    ctx->dbg[nm] = {cur, (int64_t)C * B * k2.Ho * k2.Wo * k2.cout};
+                    if (ctx->stop_stage == nm) { final_cur = cur; return 1; }    // debug early-out: buffers rotate, views alias
+                }
             }
         }
-    }
+        final_cur = cur;
+        // input_proj (1x1 convolution, detr_vae.py:184) of the range's layer4 maps, rows scattered to their tokens
+        GemmArgs ip = linear_args(cur, 8 * w0, nc * B * ctx->P_, 8 * w0, ctx->P("input_proj.weight"), D, ctx->P("input_proj.bias"),
+                                  ctx->X, D);
+        ip.rowmap = ctx->rowmap + (int64_t)c0 * B * ctx->P_;
+        return ctx_gemm(ctx, ip, ls, half);
+    };
     if (ctx->rowmap_B != B) {
         CHK(launch_build_rowmap(ctx->rowmap, B, C, ctx->fh, ctx->fw, ctx->N, st));
         ctx->rowmap_B = B;
     }
-    GemmArgs ip = linear_args(cur, 8 * w0, C * B * ctx->P_, 8 * w0, ctx->P("input_proj.weight"), D,
-                              ctx->P("input_proj.bias"), ctx->X, D);
-    ip.rowmap = ctx->rowmap;
-    CHK(ctx_gemm(ctx, ip, st));
+    if (pipe) {
+        // two camera halves as two parallel branches: when one half's launch runs out of workgroups (layer3: 300 per half on
+        // 512 slots) the other half's current launch fills the CUs, and no launch boundary drains the whole chip
+        ctx->policy_mult = 2;
+        HIPCHK(hipEventRecord(ctx->ev_pfork, st));
+        HIPCHK(hipStreamWaitEvent(ctx->pipe_stream, ctx->ev_pfork, 0));
+        int rc = run_layers(C / 2, C - C / 2, ctx->pipe_stream, 1);
+        if (rc == 0) rc = run_layers(0, C / 2, st, 0);
+        ctx->policy_mult = 1;
+        HIPCHK(hipEventRecord(ctx->ev_pjoin, ctx->pipe_stream));
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_pjoin, 0));
+        if (rc != 0) return rc;
+    } else {
+        const int rc = run_layers(0, C, st, -1);
+        if (rc != 0) return rc;
+    }
+    (void)final_cur;
     return 0;
 }
 

@@ -239,6 +239,10 @@ class InferRig:
         self.torch.cuda.empty_cache()
 
 
+LAUNCH_NOTE = ("" if os.environ.get("ACTMI_CAM_PIPE") == "0" else
+               "; the ResNet trunk runs as two concurrent branches of the graph (camera halves on two streams)")
+
+
 def kernel_table(prof, steps):
     prof = [p for p in prof if p["ms"] > 0]
     prof.sort(key=lambda p: -p["ms"])
@@ -266,9 +270,19 @@ def profile_eager(rig, steps):
     return L.profile_report()
 
 
-def sub_record(cfg, B, dev, steps, warmup, prec=None, note=""):
-    """One driver-visible sub-record: ms/step, policy steps/s and the dominant kernel's roofline fraction at batch B."""
-    rig = InferRig(cfg, B, dev, seed=4321 + B, prec=prec)
+def sub_record(cfg, B, dev, steps, warmup, prec=None, note="", env=None):
+    """One driver-visible sub-record: ms/step, policy steps/s and the dominant kernel's roofline fraction at batch B.
+    env: environment settings read by the engine at create (restored afterwards)."""
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        rig = InferRig(cfg, B, dev, seed=4321 + B, prec=prec)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     dt = rig.timed(steps, warmup)
     prof, rows, gpu_ms = kernel_table(profile_eager(rig, max(3, steps // 2)), max(3, steps // 2))
     dom, ach = dominant(prof)
@@ -376,8 +390,11 @@ def bench_infer(args, cfg, B, ctx):
         "config": {"workload": "ACT eval policy query: 4 cams 480x640 u8, chunk 100, hidden 512, ff 3200, "
                                "4 enc + 7 dec layers (layer 0 live), per-GPU batch %d, + temporal ensemble" % B,
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"replicas x{world}",
-                   "launch": "hipGraph replay" if rig.graphed else "eager"},
+                   "launch": ("hipGraph replay" if rig.graphed else "eager") + LAUNCH_NOTE},
         "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                     "measured": "per-launch HIP events on the launch stream, launches back to back on ONE stream (the profiled "
+                                 "steps run the trunk as a single branch: events cannot bracket a launch that overlaps "
+                                 "another branch's); extra.single_branch times the whole step that way",
                      "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source, "peak_is": peak_is,
                      "frac_of_native_fp32_mfma_peak": ach / PEAK_FP32_MATRIX_TFLOPS,
                      "avg_launch_us": dom["ms"] * 1e3 / dom["count"], "launches_per_step": dom["count"] / args.steps,
@@ -403,6 +420,10 @@ def bench_infer(args, cfg, B, ctx):
                          ("b50", lambda: sub_record(cfg, 50, dev, 6, 2, note="config 2's batch (50 parallel episodes), 4 cameras")),
                          ("native_fp32", lambda: sub_record(cfg, B, dev, 10, 2, prec="f32",
                                                             note="every product on the exact fp32 MFMA (gemm_prec=f32)")),
+                         ("single_branch", lambda: sub_record(cfg, B, dev, args.steps, args.warmup, env={"ACTMI_CAM_PIPE": "0"},
+                                                              note="ACTMI_CAM_PIPE=0: every launch of the ResNet trunk spans all "
+                                                                   "cameras, one stream (the launch structure the roofline "
+                                                                   "record and the rocprofv3 summaries describe)")),
                          ("train_b64", lambda: train_record(cfg, 64, dev, 4, 2)),
                          ("diffusion_b32", lambda: diffusion_record(dev, 32, 3, 1))):
             try:

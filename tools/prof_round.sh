@@ -6,11 +6,14 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 30 --warmup 5 > $O/bench_infer.json 2> $O/bench_infer.err
 echo bench done >&2
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --no-cpu-baseline --no-extras --sustained-s 0 --steps 30 --warmup 5 > $O/bench_under_rocprof.json 2>/dev/null
+ACTMI_CAM_PIPE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --no-cpu-baseline --no-extras --sustained-s 0 --steps 30 --warmup 5 > $O/bench_under_rocprof.json 2>/dev/null
 echo kt done >&2
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pf -o pf -- python3 $R/bench.py --no-cpu-baseline --no-extras --sustained-s 0 --no-graph --steps 3 --warmup 1 > /dev/null 2>&1
+# the default launch structure (trunk as two concurrent camera branches): per-kernel durations overlap here
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_pipe -o kt -- python3 $R/bench.py --no-cpu-baseline --no-extras --sustained-s 0 --steps 30 --warmup 5 > $O/bench_under_rocprof_pipe.json 2>/dev/null
+echo kt_pipe done >&2
+ACTMI_CAM_PIPE=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pf -o pf -- python3 $R/bench.py --no-cpu-baseline --no-extras --sustained-s 0 --no-graph --steps 3 --warmup 1 > /dev/null 2>&1
 echo pf done >&2
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pw -o pw -- python3 $R/bench.py --no-cpu-baseline --no-extras --sustained-s 0 --no-graph --steps 3 --warmup 1 > /dev/null 2>&1
+ACTMI_CAM_PIPE=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pw -o pw -- python3 $R/bench.py --no-cpu-baseline --no-extras --sustained-s 0 --no-graph --steps 3 --warmup 1 > /dev/null 2>&1
 echo pw done >&2
 python3 $R/bench.py --shapes --no-extras --no-cpu-baseline --sustained-s 0 --steps 30 --warmup 5 > $O/bench_shapes.json 2>/dev/null
 find $O -name "*.csv" | head -20 >&2
