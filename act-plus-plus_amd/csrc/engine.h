@@ -122,6 +122,7 @@ struct actmi_ctx {
     hipStream_t pipe_stream = nullptr;
     hipEvent_t ev_pfork = nullptr, ev_pjoin = nullptr;
     bool cam_pipe = false;
+    int last_B = 0;                    // batch of the forward in flight (debug views)
     int policy_mult = 1;               // split-K policy counts the tiles of the WHOLE camera set while a half is being launched
     bool conv_direct = false;          // layer2-4 stride-1 3x3 convolutions on the direct kernel (conv3g.hip): measured slower, opt-in
     int conv_direct_min_images = 8;    // below this many images (cameras x batch) its grid is too small: implicit GEMM + split-K

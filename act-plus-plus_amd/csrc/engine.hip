@@ -789,78 +789,100 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
     return 0;
 }
 
+// The transformer's activation buffers as seen by one branch: the samples [b0, b0 + nb) of the batch (token-major [B][N][D]
+// layouts: a batch range is a pointer offset).  half >= 0: one of two concurrent branches (own half of the slice workspace).
+struct TView {
+    float *X, *QKV, *ATT, *Y, *X1, *Hb, *dO, *dY, *dT2, *dH, *hs, *attn_ws;
+    int64_t attn_ws_floats;
+    int half;
+};
+static TView make_view(const actmi_ctx* ctx, int b0, int nb, int half) {
+    const actmi_config& g = ctx->cfg;
+    const int64_t D = g.hidden_dim, F = g.dim_feedforward, Q = g.num_queries, N = ctx->N;
+    const int64_t ws_per = ctx->attn_ws_floats / g.max_batch;
+    TView v;
+    v.X = ctx->X + b0 * N * D; v.QKV = ctx->QKV + b0 * N * 3 * D; v.ATT = ctx->ATT + b0 * N * D; v.Y = ctx->Y + b0 * N * D;
+    v.X1 = ctx->X1 + b0 * N * D; v.Hb = ctx->Hb + b0 * N * F;
+    v.dO = ctx->dO + b0 * Q * D; v.dY = ctx->dY + b0 * Q * D; v.dT2 = ctx->dT2 + b0 * Q * D; v.dH = ctx->dH + b0 * Q * F;
+    v.hs = ctx->hs + b0 * Q * D;
+    v.attn_ws = ctx->attn_ws + b0 * ws_per; v.attn_ws_floats = (half < 0) ? ctx->attn_ws_floats : nb * ws_per;
+    v.half = half;
+    return v;
+}
+
 // one post-norm encoder layer on x [B*n][D] in place (transformer.py:211-224)
-int engine_encoder_layer(actmi_ctx* ctx, const EncW& w, float* x, const float* pos, int B, int n, const uint8_t* kpm,
+int engine_encoder_layer(actmi_ctx* ctx, const EncW& w, const TView& V, const float* pos, int B, int n, const uint8_t* kpm,
                          hipStream_t st) {
+    float* x = V.X;
     const actmi_config& g = ctx->cfg;
     const int D = g.hidden_dim, F = g.dim_feedforward, M = B * n, hd = D / g.nheads;
-    GemmArgs qkv = linear_args(x, D, M, D, w.attn.in_w, 3 * D, w.attn.in_b, ctx->QKV, 3 * D);
+    GemmArgs qkv = linear_args(x, D, M, D, w.attn.in_w, 3 * D, w.attn.in_b, V.QKV, 3 * D);
     qkv.A_add = pos; qkv.ld_add = D; qkv.add_mod = n; qkv.add_ncols = 2 * D;     // q = k = x + pos, v = x
-    CHK(ctx_gemm(ctx, qkv, st));
+    CHK(ctx_gemm(ctx, qkv, st, V.half));
     AttnArgs at;
     memset(&at, 0, sizeof(at));
-    at.Q = ctx->QKV; at.q_bs = (int64_t)n * 3 * D; at.q_rs = 3 * D;
-    at.K = ctx->QKV + D; at.k_bs = at.q_bs; at.k_rs = 3 * D;
-    at.V = ctx->QKV + 2 * D; at.v_bs = at.q_bs; at.v_rs = 3 * D;
-    at.O = ctx->ATT; at.o_bs = (int64_t)n * D; at.o_rs = D;
+    at.Q = V.QKV; at.q_bs = (int64_t)n * 3 * D; at.q_rs = 3 * D;
+    at.K = V.QKV + D; at.k_bs = at.q_bs; at.k_rs = 3 * D;
+    at.V = V.QKV + 2 * D; at.v_bs = at.q_bs; at.v_rs = 3 * D;
+    at.O = V.ATT; at.o_bs = (int64_t)n * D; at.o_rs = D;
     at.kpm = kpm; at.kpm_bs = n;
     at.B = B; at.H = g.nheads; at.Nq = n; at.Nk = n; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
-    at.ws = ctx->attn_ws; at.ws_floats = ctx->attn_ws_floats;
+    at.ws = V.attn_ws; at.ws_floats = V.attn_ws_floats;
     at.prec = ctx->gemm_prec;
     CHK(launch_attention(at, st, &ctx->err));
-    GemmArgs op = linear_args(ctx->ATT, D, M, D, w.attn.out_w, D, w.attn.out_b, ctx->Y, D);
+    GemmArgs op = linear_args(V.ATT, D, M, D, w.attn.out_w, D, w.attn.out_b, V.Y, D);
     op.res = x; op.ldres = D;
-    CHK(ctx_gemm(ctx, op, st));
-    CHK(launch_layernorm(ctx->Y, nullptr, 0, w.n1w, w.n1b, nullptr, nullptr, ctx->X1, M, D, 1e-5f, st, &ctx->err));
-    GemmArgs f1 = linear_args(ctx->X1, D, M, D, w.l1w, F, w.l1b, ctx->Hb, F);
+    CHK(ctx_gemm(ctx, op, st, V.half));
+    CHK(launch_layernorm(V.Y, nullptr, 0, w.n1w, w.n1b, nullptr, nullptr, V.X1, M, D, 1e-5f, st, &ctx->err));
+    GemmArgs f1 = linear_args(V.X1, D, M, D, w.l1w, F, w.l1b, V.Hb, F);
     f1.relu = 1;
-    CHK(ctx_gemm(ctx, f1, st));
-    GemmArgs f2 = linear_args(ctx->Hb, F, M, F, w.l2w, D, w.l2b, ctx->Y, D);
-    f2.res = ctx->X1; f2.ldres = D;
-    CHK(ctx_gemm(ctx, f2, st));
-    CHK(launch_layernorm(ctx->Y, nullptr, 0, w.n2w, w.n2b, nullptr, nullptr, x, M, D, 1e-5f, st, &ctx->err));
+    CHK(ctx_gemm(ctx, f1, st, V.half));
+    GemmArgs f2 = linear_args(V.Hb, F, M, F, w.l2w, D, w.l2b, V.Y, D);
+    f2.res = V.X1; f2.ldres = D;
+    CHK(ctx_gemm(ctx, f2, st, V.half));
+    CHK(launch_layernorm(V.Y, nullptr, 0, w.n2w, w.n2b, nullptr, nullptr, x, M, D, 1e-5f, st, &ctx->err));
     return 0;
 }
 
 // decoder layer 0 with the constant query path + heads (transformer.py:274-295,175; detr_vae.py:245,252)
-int engine_decoder_infer(actmi_ctx* ctx, int B, float* a_hat, hipStream_t st) {
+int engine_decoder_infer(actmi_ctx* ctx, const TView& V, int B, float* a_hat, hipStream_t st) {
     const actmi_config& g = ctx->cfg;
     const int D = g.hidden_dim, F = g.dim_feedforward, Q = g.num_queries, N = ctx->N, hd = D / g.nheads;
     const DecW& d = ctx->dec[0];
-    float* KV = ctx->QKV;   // [B*N][2D]
-    GemmArgs kv = linear_args(ctx->X, D, B * N, D, d.cross.in_w + (int64_t)D * D, 2 * D, d.cross.in_b + D, KV, 2 * D);
+    float* KV = V.QKV;   // [B*N][2D]
+    GemmArgs kv = linear_args(V.X, D, B * N, D, d.cross.in_w + (int64_t)D * D, 2 * D, d.cross.in_b + D, KV, 2 * D);
     kv.A_add = ctx->pos_tokens; kv.ld_add = D; kv.add_mod = N; kv.add_ncols = D;      // k = memory + pos, v = memory
-    CHK(ctx_gemm(ctx, kv, st));
+    CHK(ctx_gemm(ctx, kv, st, V.half));
     AttnArgs at;
     memset(&at, 0, sizeof(at));
     at.Q = ctx->dec_q; at.q_bs = 0; at.q_rs = D;
     at.K = KV; at.k_bs = (int64_t)N * 2 * D; at.k_rs = 2 * D;
     at.V = KV + D; at.v_bs = at.k_bs; at.v_rs = 2 * D;
-    at.O = ctx->dO; at.o_bs = (int64_t)Q * D; at.o_rs = D;
+    at.O = V.dO; at.o_bs = (int64_t)Q * D; at.o_rs = D;
     at.B = B; at.H = g.nheads; at.Nq = Q; at.Nk = N; at.HD = hd; at.scale = 1.0f / sqrtf((float)hd);
-    at.ws = ctx->attn_ws; at.ws_floats = ctx->attn_ws_floats;
+    at.ws = V.attn_ws; at.ws_floats = V.attn_ws_floats;
     at.prec = ctx->gemm_prec;
     CHK(launch_attention(at, st, &ctx->err));
     const int M = B * Q;
-    GemmArgs op = linear_args(ctx->dO, D, M, D, d.cross.out_w, D, d.cross.out_b, ctx->dY, D);
+    GemmArgs op = linear_args(V.dO, D, M, D, d.cross.out_w, D, d.cross.out_b, V.dY, D);
     op.res = ctx->dec_t1; op.ldres = D; op.res_mod = 1;
-    CHK(ctx_gemm(ctx, op, st));
-    CHK(launch_layernorm(ctx->dY, nullptr, 0, d.n2w, d.n2b, nullptr, nullptr, ctx->dT2, M, D, 1e-5f, st, &ctx->err));
-    GemmArgs f1 = linear_args(ctx->dT2, D, M, D, d.l1w, F, d.l1b, ctx->dH, F);
+    CHK(ctx_gemm(ctx, op, st, V.half));
+    CHK(launch_layernorm(V.dY, nullptr, 0, d.n2w, d.n2b, nullptr, nullptr, V.dT2, M, D, 1e-5f, st, &ctx->err));
+    GemmArgs f1 = linear_args(V.dT2, D, M, D, d.l1w, F, d.l1b, V.dH, F);
     f1.relu = 1;
-    CHK(ctx_gemm(ctx, f1, st));
-    GemmArgs f2 = linear_args(ctx->dH, F, M, F, d.l2w, D, d.l2b, ctx->dY, D);
-    f2.res = ctx->dT2; f2.ldres = D;
-    CHK(ctx_gemm(ctx, f2, st));
-    CHK(launch_layernorm(ctx->dY, nullptr, 0, d.n3w, d.n3b, ctx->P("transformer.decoder.norm.weight"),
-                         ctx->P("transformer.decoder.norm.bias"), ctx->hs, M, D, 1e-5f, st, &ctx->err));
-    GemmArgs ah = linear_args(ctx->hs, D, M, D, ctx->P("action_head.weight"), g.action_dim, ctx->P("action_head.bias"),
+    CHK(ctx_gemm(ctx, f1, st, V.half));
+    GemmArgs f2 = linear_args(V.dH, F, M, F, d.l2w, D, d.l2b, V.dY, D);
+    f2.res = V.dT2; f2.ldres = D;
+    CHK(ctx_gemm(ctx, f2, st, V.half));
+    CHK(launch_layernorm(V.dY, nullptr, 0, d.n3w, d.n3b, ctx->P("transformer.decoder.norm.weight"),
+                         ctx->P("transformer.decoder.norm.bias"), V.hs, M, D, 1e-5f, st, &ctx->err));
+    GemmArgs ah = linear_args(V.hs, D, M, D, ctx->P("action_head.weight"), g.action_dim, ctx->P("action_head.bias"),
                               a_hat, g.action_dim);
     // default-on output guard: an operand that left the fp16 range of the f16x3 products surfaces as inf / NaN in a_hat;
     // the action head's epilogue raises the flag (read at the caller's next natural synchronisation: actmi_get_flags)
     ah.finite_flag = ctx->flags; ah.finite_bit = ACTMI_FLAG_OUTPUT;
-    CHK(ctx_gemm(ctx, ah, st));
-    ctx->dbg["hs"] = {ctx->hs, (int64_t)M * D};
+    CHK(ctx_gemm(ctx, ah, st, V.half));
+    if (V.half <= 0) ctx->dbg["hs"] = {ctx->hs, (int64_t)ctx->last_B * Q * D};
     return 0;
 }
 
@@ -893,9 +915,29 @@ int engine_forward_infer(actmi_ctx* ctx, const float* qpos, const void* image, i
                             ctx->P("latent_out_proj.bias"), 0));
     ctx->dbg["src"] = {ctx->X, (int64_t)B * N * D};
     if (ctx->stop_stage == "src") return 0;
-    for (int l = 0; l < g.enc_layers; ++l)
-        CHK(engine_encoder_layer(ctx, ctx->enc[l], ctx->X, ctx->pos_tokens, B, N, nullptr, st));
+    ctx->last_B = B;
+    auto run_transformer = [&](int b0, int nb, hipStream_t ts, int half) -> int {
+        const TView V = make_view(ctx, b0, nb, half);
+        for (int l = 0; l < g.enc_layers; ++l)
+            CHK(engine_encoder_layer(ctx, ctx->enc[l], V, ctx->pos_tokens, nb, N, nullptr, ts));
+        return engine_decoder_infer(ctx, V, nb, a_hat + (int64_t)b0 * g.num_queries * g.action_dim, ts);
+    };
+    // encoder + decoder as two concurrent branches over the two halves of the batch (samples are independent): the 304-workgroup
+    // launches (out-proj, FFN2: 59 % of the 512 residency slots) of one half run beside the other half's launches
+    const bool tpipe = ctx->cam_pipe && ctx->pipe_stream && B >= 2 && !prof_enabled() && ctx->stop_stage.empty();
     ctx->dbg["memory"] = {ctx->X, (int64_t)B * N * D};
-    CHK(engine_decoder_infer(ctx, B, a_hat, st));
+    if (tpipe) {
+        ctx->policy_mult = 2;
+        HIPCHK(hipEventRecord(ctx->ev_pfork, st));
+        HIPCHK(hipStreamWaitEvent(ctx->pipe_stream, ctx->ev_pfork, 0));
+        int rc = run_transformer(B / 2, B - B / 2, ctx->pipe_stream, 1);
+        if (rc == 0) rc = run_transformer(0, B / 2, st, 0);
+        ctx->policy_mult = 1;
+        HIPCHK(hipEventRecord(ctx->ev_pjoin, ctx->pipe_stream));
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_pjoin, 0));
+        if (rc != 0) return rc;
+    } else {
+        CHK(run_transformer(0, B, st, -1));
+    }
     return 0;
 }
