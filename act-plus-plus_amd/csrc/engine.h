@@ -119,8 +119,11 @@ struct actmi_ctx {
     bool ds_fork = true;
     // two camera halves of the ResNet trunk as two parallel branches (second stream): the tail of one half's launch is
     // filled by the other half's next launch (default on, ACTMI_CAM_PIPE=0 disables; engine_backbone)
-    hipStream_t pipe_stream = nullptr;
+    hipStream_t pipe_stream = nullptr;             // branch 1 (non-null = branches available)
+    hipStream_t pipe_streams[3] = {nullptr, nullptr, nullptr};     // branches 1 .. nbranch-1 (pipe_streams[0] == pipe_stream)
     hipEvent_t ev_pfork = nullptr, ev_pjoin = nullptr;
+    hipEvent_t ev_pjoins[3] = {nullptr, nullptr, nullptr};
+    int nbranch = 2;                   // ACTMI_BRANCHES (2 .. 4)
     bool cam_pipe = false;
     int last_B = 0;                    // batch of the forward in flight (debug views)
     int policy_mult = 1;               // split-K policy counts the tiles of the WHOLE camera set while a half is being launched

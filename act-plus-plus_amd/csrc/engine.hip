@@ -156,8 +156,9 @@ int dev_alloc(actmi_ctx* ctx, float** p, int64_t nfloats) {
 int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half) {
     a.prec = ctx->gemm_prec;
     // ws_half 0 / 1: this launch belongs to one of two concurrent branches, each with its own half of the slice workspace
-    float* const ws = ctx->splitk_ws ? ctx->splitk_ws + (ws_half > 0 ? ctx->splitk_ws_floats / 2 : 0) : nullptr;
-    const int64_t ws_floats = ws_half >= 0 ? ctx->splitk_ws_floats / 2 : ctx->splitk_ws_floats;
+    const int64_t ws_part = (ctx->splitk_ws_floats / ctx->nbranch) & ~(int64_t)3;
+    float* const ws = ctx->splitk_ws ? ctx->splitk_ws + (ws_half > 0 ? ws_half * ws_part : 0) : nullptr;
+    const int64_t ws_floats = ws_half >= 0 ? ws_part : ctx->splitk_ws_floats;
     if (ctx->gemm_prec == ACTMI_PREC_F16X3 && a.tb == 0) {
         // B is a weight matrix: use its pre-split image (same offsets) where one exists
         if (a.Bw >= ctx->pbase && a.Bw < ctx->pbase + ctx->ptotal) {
@@ -517,11 +518,16 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
         }
         const char* e5 = getenv("ACTMI_CAM_PIPE");
         ctx->cam_pipe = !(e5 && e5[0] == '0');             // default on; ACTMI_CAM_PIPE=0: one branch (every launch spans all cameras)
-        if (ctx->cam_pipe && (hipStreamCreateWithFlags(&ctx->pipe_stream, hipStreamNonBlocking) != hipSuccess ||
-                              hipEventCreateWithFlags(&ctx->ev_pfork, hipEventDisableTiming) != hipSuccess ||
-                              hipEventCreateWithFlags(&ctx->ev_pjoin, hipEventDisableTiming) != hipSuccess)) {
-            ctx->err = "cannot create the camera-pipeline stream";
-            return fail(ACTMI_E_LAUNCH);
+        if (const char* e6 = getenv("ACTMI_BRANCHES")) ctx->nbranch = atoi(e6);
+        if (ctx->nbranch < 2) ctx->nbranch = 2;
+        if (ctx->nbranch > 4) ctx->nbranch = 4;
+        if (ctx->cam_pipe) {
+            bool ok = hipEventCreateWithFlags(&ctx->ev_pfork, hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; ok && i < ctx->nbranch - 1; ++i)
+                ok = hipStreamCreateWithFlags(&ctx->pipe_streams[i], hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&ctx->ev_pjoins[i], hipEventDisableTiming) == hipSuccess;
+            if (!ok) { ctx->err = "cannot create the branch streams"; return fail(ACTMI_E_LAUNCH); }
+            ctx->pipe_stream = ctx->pipe_streams[0];
         }
     }
     ctx->finalized = false;
@@ -537,8 +543,10 @@ int engine_destroy(actmi_ctx* ctx) {
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->ev_pfork) (void)hipEventDestroy(ctx->ev_pfork);
-    if (ctx->ev_pjoin) (void)hipEventDestroy(ctx->ev_pjoin);
-    if (ctx->pipe_stream) (void)hipStreamDestroy(ctx->pipe_stream);
+    for (int i = 0; i < 3; ++i) {
+        if (ctx->ev_pjoins[i]) (void)hipEventDestroy(ctx->ev_pjoins[i]);
+        if (ctx->pipe_streams[i]) (void)hipStreamDestroy(ctx->pipe_streams[i]);
+    }
     if (ctx->train && ctx->train->ev_phase1) (void)hipEventDestroy(ctx->train->ev_phase1);
     delete ctx->train;
     delete ctx;
@@ -772,14 +780,20 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
     if (pipe) {
         // two camera halves as two parallel branches: when one half's launch runs out of workgroups (layer3: 300 per half on
         // 512 slots) the other half's current launch fills the CUs, and no launch boundary drains the whole chip
-        ctx->policy_mult = 2;
+        // branch i takes the cameras [i C / nb, (i+1) C / nb); branch 0 runs on the caller's stream
+        const int nb = C < ctx->nbranch ? C : ctx->nbranch;
+        ctx->policy_mult = nb;
         HIPCHK(hipEventRecord(ctx->ev_pfork, st));
-        HIPCHK(hipStreamWaitEvent(ctx->pipe_stream, ctx->ev_pfork, 0));
-        int rc = run_layers(C / 2, C - C / 2, ctx->pipe_stream, 1);
-        if (rc == 0) rc = run_layers(0, C / 2, st, 0);
+        int rc = 0;
+        for (int i = nb - 1; i >= 0 && rc == 0; --i) {
+            const int c0 = i * C / nb, c1 = (i + 1) * C / nb;
+            hipStream_t bs = i ? ctx->pipe_streams[i - 1] : st;
+            if (i) HIPCHK(hipStreamWaitEvent(bs, ctx->ev_pfork, 0));
+            rc = run_layers(c0, c1 - c0, bs, i);
+            if (i) HIPCHK(hipEventRecord(ctx->ev_pjoins[i - 1], bs));
+        }
+        for (int i = 1; i < nb; ++i) HIPCHK(hipStreamWaitEvent(st, ctx->ev_pjoins[i - 1], 0));     // join (after branch 0 is queued)
         ctx->policy_mult = 1;
-        HIPCHK(hipEventRecord(ctx->ev_pjoin, ctx->pipe_stream));
-        HIPCHK(hipStreamWaitEvent(st, ctx->ev_pjoin, 0));
         if (rc != 0) return rc;
     } else {
         const int rc = run_layers(0, C, st, -1);
@@ -927,14 +941,19 @@ int engine_forward_infer(actmi_ctx* ctx, const float* qpos, const void* image, i
     const bool tpipe = ctx->cam_pipe && ctx->pipe_stream && B >= 2 && !prof_enabled() && ctx->stop_stage.empty();
     ctx->dbg["memory"] = {ctx->X, (int64_t)B * N * D};
     if (tpipe) {
-        ctx->policy_mult = 2;
+        const int nb = B < ctx->nbranch ? B : ctx->nbranch;
+        ctx->policy_mult = nb;
         HIPCHK(hipEventRecord(ctx->ev_pfork, st));
-        HIPCHK(hipStreamWaitEvent(ctx->pipe_stream, ctx->ev_pfork, 0));
-        int rc = run_transformer(B / 2, B - B / 2, ctx->pipe_stream, 1);
-        if (rc == 0) rc = run_transformer(0, B / 2, st, 0);
+        int rc = 0;
+        for (int i = nb - 1; i >= 0 && rc == 0; --i) {
+            const int b0 = i * B / nb, b1 = (i + 1) * B / nb;
+            hipStream_t bs = i ? ctx->pipe_streams[i - 1] : st;
+            if (i) HIPCHK(hipStreamWaitEvent(bs, ctx->ev_pfork, 0));
+            rc = run_transformer(b0, b1 - b0, bs, i);
+            if (i) HIPCHK(hipEventRecord(ctx->ev_pjoins[i - 1], bs));
+        }
+        for (int i = 1; i < nb; ++i) HIPCHK(hipStreamWaitEvent(st, ctx->ev_pjoins[i - 1], 0));     // join (after branch 0 is queued)
         ctx->policy_mult = 1;
-        HIPCHK(hipEventRecord(ctx->ev_pjoin, ctx->pipe_stream));
-        HIPCHK(hipStreamWaitEvent(st, ctx->ev_pjoin, 0));
         if (rc != 0) return rc;
     } else {
         CHK(run_transformer(0, B, st, -1));

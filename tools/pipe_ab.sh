@@ -1,7 +1,7 @@
 R=$GRAFT_REPO_ROOT
-for cfg in "ACTMI_CAM_PIPE=0" "base" "ACTMI_CAM_PIPE=0" "base"; do
-  for b in 8 2 50; do
-    st=60; [ $b = 2 ] && st=200; [ $b = 50 ] && st=12
+for cfg in "base" "ACTMI_BRANCHES=3" "ACTMI_BRANCHES=4" "base" "ACTMI_BRANCHES=3" "ACTMI_BRANCHES=4"; do
+  for b in 8 1 50; do
+    st=60; [ $b = 1 ] && st=200; [ $b = 50 ] && st=12
     if [ "$cfg" = "base" ]; then
       python3 $R/bench.py --batch $b --steps $st --warmup 10 --no-cpu-baseline --no-extras --sustained-s 0 2>/dev/null > /tmp/o.json
     else
