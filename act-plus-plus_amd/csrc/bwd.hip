@@ -621,9 +621,15 @@ int launch_ln_bwd(const float* x, const float* w, const float* dy, const float* 
 
 // gather form on the recorded argmax codes (maxpool_idx_kernel): an input element (hi, wi) lies in at most 2 x 2 windows;
 // it receives dy of those whose code names its position
+// relu_x / bn_scale (optional): the ReLU + FrozenBN backward of the stem folded in -- dx = pooled gradient * (relu_x > 0) *
+// bn_scale[group][c] (group = image / imgs_per_group), amax_bits = bits of max |dx| -- instead of a second pass over the
+// largest map of the network
 __global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const uint8_t* __restrict__ arg, const float* __restrict__ dy,
                                                               float* __restrict__ dx, int H, int W, int C4, int Ho, int Wo,
-                                                              unsigned total) {
+                                                              unsigned total, const float* __restrict__ relu_x,
+                                                              const float* __restrict__ bn_scale, int imgs_per_group,
+                                                              unsigned* __restrict__ amax_bits) {
+    unsigned amx = 0;
     for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const unsigned pix0 = idx / (unsigned)C4;
         const int c4 = (int)(idx - pix0 * (unsigned)C4);
@@ -649,19 +655,33 @@ __global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const uint8_t* __r
                 if (a.w == me) acc[3] += g[3];
             }
         }
+        if (relu_x) {
+            const f32x4 xv = reinterpret_cast<const f32x4*>(relu_x)[idx];
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(bn_scale + ((int64_t)(img / (unsigned)imgs_per_group) * C4 + c4) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[e] = xv[e] > 0.f ? acc[e] * sc[e] : 0.f;
+                amx = max(amx, __float_as_uint(acc[e]) & 0x7fffffffu);
+            }
+        }
         reinterpret_cast<f32x4*>(dx)[idx] = acc;
+    }
+    if (amax_bits) {
+        for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o, 64));
+        if ((threadIdx.x & 63) == 0 && amx) amax_commit(amax_bits, amx);
     }
 }
 
 int launch_maxpool_bwd_idx(const uint8_t* arg, const float* dy, float* dx, int nimg, int H, int W, int C, int Ho, int Wo,
-                           hipStream_t st) {
+                           hipStream_t st, const float* relu_x, const float* bn_scale, int imgs_per_group, unsigned* amax_bits) {
     if (C & 3) return -2;
     const int64_t total = (int64_t)nimg * H * W * (C / 4);
     if (total >= ((int64_t)1 << 31)) return -2;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     prof_begin("maxpool_bwd_idx_kernel", 0.0, 4.0 * nimg * C * ((double)H * W + 1.25 * Ho * Wo), st);
-    hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3((unsigned)blocks), dim3(256), 0, st, arg, dy, dx, H, W, C / 4, Ho, Wo, (unsigned)total);
+    hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3((unsigned)blocks), dim3(256), 0, st, arg, dy, dx, H, W, C / 4, Ho, Wo, (unsigned)total,
+                       relu_x, bn_scale, imgs_per_group > 0 ? imgs_per_group : 1, amax_bits);
     prof_end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

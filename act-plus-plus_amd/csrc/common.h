@@ -115,7 +115,8 @@ int launch_maxpool(const float* in, float* out, int nimg, int H, int W, int C, i
 int launch_hpool(const float* in, float* out, int nrows, int W, int C, int Wo, hipStream_t st);
 int launch_maxpool_idx(const float* in, float* out, uint8_t* arg, int nimg, int H, int W, int C, int Ho, int Wo, hipStream_t st);
 int launch_maxpool_bwd_idx(const uint8_t* arg, const float* dy, float* dx, int nimg, int H, int W, int C, int Ho, int Wo,
-                           hipStream_t st);
+                           hipStream_t st, const float* relu_x = nullptr, const float* bn_scale = nullptr, int imgs_per_group = 1,
+                           unsigned* amax_bits = nullptr);
 
 // ---- LayerNorm (layernorm.hip) ----------------------------------------------------------------
 // y = LN(x + res[m % res_mod]) * w + b ; optional second LN (w2,b2) applied on top.

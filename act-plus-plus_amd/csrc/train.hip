@@ -979,9 +979,9 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
         }
     }
     // stem: maxpool, relu, bn1, conv1 weight gradient through the NHWC4 normalised image
-    CHK(launch_maxpool_bwd_idx(T.pool_arg, gcur, T.g_act1, C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
-    CHK(launch_relu_bn_bwd(T.g_act1, nullptr, ctx->act1, ctx->conv1_scale, nullptr, T.g_act1, C,
-                           (int64_t)B * ctx->H1 * ctx->W1 * w0, w0, st, amax_pre(ctx, T.g_act1, st)));
+    // (ReLU + FrozenBN backward of the stem and the operand-scale maximum ride on the pool's backward: one pass over the map)
+    CHK(launch_maxpool_bwd_idx(T.pool_arg, gcur, T.g_act1, C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st, ctx->act1,
+                               ctx->conv1_scale, B, amax_pre(ctx, T.g_act1, st)));
     {
         GemmArgs a = G0();
         a.A = T.g_act1; a.lda = w0; a.ta = 1; a.M = w0; a.K = B * ctx->H1 * ctx->W1;
