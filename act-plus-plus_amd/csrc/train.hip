@@ -125,6 +125,14 @@ const float* dyn_scale(actmi_ctx* ctx, const float* x, int64_t ld, int M, int N,
     return slot;
 }
 
+// a fresh scale slot for a caller that manages it by hand: slot[0] = the scale (after launch_pow2_from_bits), slot[1] = the bits
+// word the producers raise (zero between uses)
+float* scale_slot(actmi_ctx* ctx) {
+    if (ctx->gemm_prec != ACTMI_PREC_F16X3) return nullptr;
+    TrainState& T = *ctx->train;
+    return T.scale_slots + 2 * (T.scale_next++ % SCALE_SLOTS);
+}
+
 // The kernel that WRITES a gradient tensor can collect the amax bits itself (relu_bn_bwd, the GEMM epilogue: an integer
 // atomicMax, independent of arrival order): amax_pre() hands it the bits word of a fresh slot, and the dyn_scale() request
 // for that tensor then only derives the scale from it.  Returns nullptr when no scale will be asked for.
@@ -163,12 +171,13 @@ int lin_fwd(actmi_ctx* ctx, const float* x, int64_t ldx, int M, int K, const flo
 
 // dx[M][K] = dy[M][N] W[N][K] (+res) (masked by mask>0)
 int lin_dgrad(actmi_ctx* ctx, const float* dy, int64_t lddy, int M, int N, const float* W, int K, float* dx, int64_t lddx,
-              const float* res, const float* mask, hipStream_t st, float alpha = 1.f, bool dx_feeds_gemm = false) {
+              const float* res, const float* mask, hipStream_t st, float alpha = 1.f, bool dx_feeds_gemm = false,
+              const float* dy_scale = nullptr) {
     GemmArgs a = G0();
     a.A = dy; a.lda = lddy; a.M = M; a.K = N; a.N = K; a.Bw = W; a.ldb = K; a.tb = 1; a.C = dx; a.ldc = lddx;
     a.res = res; a.ldres = lddx; a.mask = mask; a.ldmask = lddx; a.alpha = alpha;
     a.b_scale = ctx->bwd_wscale;
-    a.a_scale_dev = dyn_scale(ctx, dy, lddy, M, N, st, true);
+    a.a_scale_dev = dy_scale ? dy_scale : dyn_scale(ctx, dy, lddy, M, N, st, true);
     // dx is the dY operand of the next data / weight gradient pair (same pointer, ld, M and K columns): its maximum is taken
     // in this product's epilogue
     if (dx_feeds_gemm && lddx == K) a.amax_out = amax_pre(ctx, dx, st);
@@ -183,7 +192,7 @@ struct Drop {
 
 // dW[N][K] += dy[M][N]^T x'[M][K],  x' = x + x_add[m % add_mod];  db[N] += colsum(dy)
 int lin_wgrad(actmi_ctx* ctx, const float* dy, int64_t lddy, int M, int N, const float* x, int64_t ldx, int K,
-              const float* x_add, int add_mod, float* dW, float* db, hipStream_t st) {
+              const float* x_add, int add_mod, float* dW, float* db, hipStream_t st, const float* dy_scale = nullptr) {
     if (dW) {
         GemmArgs a = G0();
         a.A = dy; a.lda = lddy; a.ta = 1; a.M = N; a.K = M; a.Bw = x; a.ldb = ldx; a.tb = 1; a.N = K;
@@ -191,7 +200,7 @@ int lin_wgrad(actmi_ctx* ctx, const float* dy, int64_t lddy, int M, int N, const
         a.C = dW; a.ldc = K;
         a.splitk = pick_splitk(N, K, 1, M);
         if (a.splitk <= 1) { a.splitk = 0; a.res = dW; a.ldres = K; }
-        a.a_scale_dev = dyn_scale(ctx, dy, lddy, M, N, st);
+        a.a_scale_dev = dy_scale ? dy_scale : dyn_scale(ctx, dy, lddy, M, N, st);
         CHK(tgemm(ctx, a, st));
     }
     if (db) CHK(colsum_d(ctx, dy, lddy, db, M, N, st));
@@ -207,6 +216,7 @@ struct AttnBwd {
     const uint8_t* kpm; int64_t kpm_bs;
     int B, H, Nq, Nk, HD;
     float drop_p; uint64_t drop_seed;
+    unsigned* out_amax;        // optional: one bits word that the dQ, dK and dV products all raise (shared operand scale of gQKV)
 };
 
 int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
@@ -250,6 +260,7 @@ int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
     v.a_scale = 256.f;          // probabilities (<= 1/(1-p)) are mostly ~1/Nk
     const float* dO_sc = dyn_scale(ctx, t.dO, D, t.B * t.Nq, D, st);
     v.b_scale_dev = dO_sc;
+    v.amax_out = t.out_amax;
     CHK(tgemm(ctx, v, st));
     // dP = dO V^T
     GemmArgs d = G0();
@@ -280,6 +291,7 @@ int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
     q.gA = pg * t.H; q.gA2 = pg; q.gB = t.k_bs; q.gB2 = t.HD; q.gC = t.dq_bs; q.gC2 = t.HD;
     const float* dS_sc = dyn_scale(ctx, dP, ldp, G * t.Nq, t.Nk, st);
     q.a_scale_dev = dS_sc;
+    q.amax_out = t.out_amax;
     CHK(tgemm(ctx, q, st));
     // dK[key][d] = sum_q dS[q][key] Q[q][d]
     GemmArgs k = G0();
@@ -287,6 +299,7 @@ int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
     k.C = t.dK; k.ldc = t.dk_rs; k.groups = G; k.groups_inner = t.H;
     k.gA = pg * t.H; k.gA2 = pg; k.gB = t.q_bs; k.gB2 = t.HD; k.gC = t.dk_bs; k.gC2 = t.HD;
     k.a_scale_dev = dS_sc;
+    k.amax_out = t.out_amax;
     CHK(tgemm(ctx, k, st));
     return 0;
 }
@@ -359,11 +372,16 @@ int enc_bwd(actmi_ctx* ctx, const EncW& w, const EncSave& s, const float* dOut, 
     t.dq_bs = t.dk_bs = t.dv_bs = bs; t.dq_rs = t.dk_rs = t.dv_rs = 3 * D;
     t.kpm = kpm; t.kpm_bs = n; t.B = B; t.H = g.nheads; t.Nq = n; t.Nk = n; t.HD = hd;
     t.drop_p = dr.p; t.drop_seed = dr.s(0);
+    // ONE operand scale for gQKV = [dQ | dK | dV]: the three products that write it raise the same bits word, and the data
+    // gradient and the two weight gradients below all use it (three strided amax passes over gQKV otherwise)
+    float* qkv_slot = scale_slot(ctx);
+    t.out_amax = qkv_slot ? reinterpret_cast<unsigned*>(qkv_slot + 1) : nullptr;
     CHK(attn_bwd(ctx, t, st));
+    if (qkv_slot && launch_pow2_from_bits(qkv_slot, st) != 0) return ACTMI_E_LAUNCH;
     // in_proj: dIn = dQKV W_in + dY1 ; dW rows [0,2D) see x+pos, rows [2D,3D) see x
-    CHK(lin_dgrad(ctx, gQKV, 3 * D, M, 3 * D, w.attn.in_w, D, dIn, D, gA, nullptr, st));
-    CHK(lin_wgrad(ctx, gQKV, 3 * D, M, 2 * D, s.x_in, D, D, pos, n, Gp(w.attn.in_w), nullptr, st));
-    CHK(lin_wgrad(ctx, gQKV + 2 * D, 3 * D, M, D, s.x_in, D, D, nullptr, 0, Gp(w.attn.in_w) + (int64_t)2 * D * D, nullptr, st));
+    CHK(lin_dgrad(ctx, gQKV, 3 * D, M, 3 * D, w.attn.in_w, D, dIn, D, gA, nullptr, st, 1.f, false, qkv_slot));
+    CHK(lin_wgrad(ctx, gQKV, 3 * D, M, 2 * D, s.x_in, D, D, pos, n, Gp(w.attn.in_w), nullptr, st, qkv_slot));
+    CHK(lin_wgrad(ctx, gQKV + 2 * D, 3 * D, M, D, s.x_in, D, D, nullptr, 0, Gp(w.attn.in_w) + (int64_t)2 * D * D, nullptr, st, qkv_slot));
     CHK(colsum_d(ctx, gQKV, 3 * D, Gp(w.attn.in_b), M, 3 * D, st));
     if (dpos2) {
         // additional_pos_embed rows: d(x+pos)[b][j] = dQK[b][j] W_in[0:2D], summed over the batch, j in {0,1}
