@@ -487,9 +487,11 @@ __global__ void repack_dgrad_w_kernel(const float* __restrict__ wf, float* __res
 
 // wgrad comes out as [G][O][(r,s,c)]; the state_dict gradient is OIHW
 __global__ void unpack_wgrad_kernel(const float* __restrict__ gp, float* __restrict__ g_oihw, int O, int I, int KH, int KW,
-                                    int kpad, int ipack, int64_t total) {
+                                    int kpad, int ipack, int64_t total, int64_t g_gp, int64_t g_out) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
+    gp += blockIdx.y * g_gp;                  // blockIdx.y = group (camera): its packed gradient and its OIHW gradient
+    g_oihw += blockIdx.y * g_out;
     const int s = (int)(idx % KW);
     int64_t rest = idx / KW;
     const int r = (int)(rest % KH); rest /= KH;
@@ -890,10 +892,11 @@ int launch_repack_dgrad_w(const float* wf, float* wd, int G, int O, int I, int K
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int launch_unpack_wgrad(const float* gp, float* g_oihw, int O, int I, int KH, int KW, int kpad, int ipack, hipStream_t st) {
+int launch_unpack_wgrad(const float* gp, float* g_oihw, int O, int I, int KH, int KW, int kpad, int ipack, hipStream_t st, int G,
+                        int64_t g_gp, int64_t g_out) {
     const int64_t total = (int64_t)O * I * KH * KW;
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gp, g_oihw, O, I, KH, KW,
-                       kpad, ipack, total);
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)((total + 255) / 256), G > 0 ? G : 1), dim3(256), 0, st, gp, g_oihw, O, I,
+                       KH, KW, kpad, ipack, total, g_gp, g_out);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

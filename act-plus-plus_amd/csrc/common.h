@@ -178,7 +178,8 @@ int launch_vq_bwd(const float* probs, const float* g, float* dlogits, int B, int
 int launch_adamw(float* p, const float* g, float* m, float* v, const uint8_t* group, int64_t n, float lr, float lr_bb,
                  float wd, float b1, float b2, float eps, int64_t step, hipStream_t st);
 int launch_repack_dgrad_w(const float* wf, float* wd, int G, int O, int I, int KK, hipStream_t st, int flip = 0);
-int launch_unpack_wgrad(const float* gp, float* g_oihw, int O, int I, int KH, int KW, int kpad, int ipack, hipStream_t st);
+int launch_unpack_wgrad(const float* gp, float* g_oihw, int O, int I, int KH, int KW, int kpad, int ipack, hipStream_t st, int G = 1,
+                        int64_t g_gp = 0, int64_t g_out = 0);
 int launch_relu_bn_bwd(const float* x, const float* add, const float* mask, const float* scale, float* y_plain,
                        float* y_scaled, int G, int64_t per_group, int C, hipStream_t st, unsigned* amax_bits = nullptr);
 int launch_normalize_pad(const void* image, int fmt, const float* lut, float* out, int B, int C, int H, int W,

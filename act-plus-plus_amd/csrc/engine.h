@@ -161,7 +161,7 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half = -1);
 int engine_destroy(actmi_ctx* ctx);
 const char* engine_create_error();
 int engine_finalize(actmi_ctx* ctx, hipStream_t st);
-int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st);
+int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st, bool after_step = false);
 int engine_calibrate_weight_scales(actmi_ctx* ctx, hipStream_t st);
 float engine_weight_scale(const actmi_ctx* ctx, const float* w);
 int train_create(actmi_ctx* ctx);

@@ -560,24 +560,30 @@ const char* engine_create_error() { return g_create_error.c_str(); }
 // ------------------------------------------------------------------------------------------------
 
 // device-side weight preparation; runs at finalize and after every optimizer step (all asynchronous on `st`)
-int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st) {
+int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st, bool after_step) {
     const actmi_config& g = ctx->cfg;
     const int C = g.num_cams, w0 = g.base_width, D = g.hidden_dim, Q = g.num_queries;
-    // conv weights OIHW -> [cam][O][(r,s,c)], FrozenBN -> scale/bias
-    for (int cam = 0; cam < C; ++cam) {
-        std::string p = "backbones." + std::to_string(cam) + ".0.body.";
-        CHK(launch_repack_conv_w(ctx->P(p + "conv1.weight"), ctx->conv1_w + (int64_t)cam * w0 * 148, 1, w0, 3, 7, 7, 0, 0,
-                                 148, st));
-        CHK(launch_bn_fold(ctx->P(p + "bn1.weight"), ctx->P(p + "bn1.bias"), ctx->P(p + "bn1.running_mean"),
-                           ctx->P(p + "bn1.running_var"), ctx->conv1_scale + cam * w0, ctx->conv1_bias + cam * w0, w0, st));
-        for (auto& cl : ctx->convs) {
-            CHK(launch_repack_conv_w(ctx->P(p + cl.name + ".weight"), cl.w + (int64_t)cam * cl.cout * cl.K, 1, cl.cout,
-                                     cl.cin, cl.k, cl.k, 0, 0, cl.K, st));
-            CHK(launch_bn_fold(ctx->P(p + cl.bn + "weight"), ctx->P(p + cl.bn + "bias"), ctx->P(p + cl.bn + "running_mean"),
-                               ctx->P(p + cl.bn + "running_var"), cl.scale + cam * cl.cout, cl.bias + cam * cl.cout,
-                               cl.cout, st));
-        }
+    // conv weights OIHW -> [cam][O][(r,s,c)]: one launch per layer over the cameras (same-named parameters of consecutive
+    // backbones are a constant stride apart in the arena)
+    {
+        const std::string p0 = "backbones.0.0.body.", p1 = "backbones." + std::to_string(C > 1 ? 1 : 0) + ".0.body.";
+        const int64_t cam_stride = ctx->P(p1 + "conv1.weight") - ctx->P(p0 + "conv1.weight");
+        CHK(launch_repack_conv_w(ctx->P(p0 + "conv1.weight"), ctx->conv1_w, C, w0, 3, 7, 7, cam_stride, (int64_t)w0 * 148, 148, st));
+        for (auto& cl : ctx->convs)
+            CHK(launch_repack_conv_w(ctx->P(p0 + cl.name + ".weight"), cl.w, C, cl.cout, cl.cin, cl.k, cl.k, cam_stride,
+                                     (int64_t)cl.cout * cl.K, cl.K, st));
     }
+    // FrozenBN -> scale / bias: buffers the optimizer never touches (reference backbone.py:21-57), so not redone after a step
+    if (!after_step)
+        for (int cam = 0; cam < C; ++cam) {
+            std::string p = "backbones." + std::to_string(cam) + ".0.body.";
+            CHK(launch_bn_fold(ctx->P(p + "bn1.weight"), ctx->P(p + "bn1.bias"), ctx->P(p + "bn1.running_mean"),
+                               ctx->P(p + "bn1.running_var"), ctx->conv1_scale + cam * w0, ctx->conv1_bias + cam * w0, w0, st));
+            for (auto& cl : ctx->convs)
+                CHK(launch_bn_fold(ctx->P(p + cl.bn + "weight"), ctx->P(p + cl.bn + "bias"), ctx->P(p + cl.bn + "running_mean"),
+                                   ctx->P(p + cl.bn + "running_var"), cl.scale + cam * cl.cout, cl.bias + cam * cl.cout,
+                                   cl.cout, st));
+        }
     if (ctx->gemm_prec == ACTMI_PREC_F16X3) {
         // per-parameter scales (engine_calibrate_weight_scales); a weight that has outgrown its scale since the last
         // finalize raises ACTMI_FLAG_WEIGHT instead of silently becoming inf

@@ -1012,14 +1012,16 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
         a.a_scale_dev = dyn_scale(ctx, T.g_act1, w0, C * B * ctx->H1 * ctx->W1, w0, st);
         CHK(tgemm(ctx, a, st));
     }
-    // packed conv gradients -> OIHW state_dict gradients
-    for (int cam = 0; cam < C; ++cam) {
-        const std::string p = "backbones." + std::to_string(cam) + ".0.body.";
-        CHK(launch_unpack_wgrad(T.conv1_gw + (int64_t)cam * w0 * 196, GP((p + "conv1.weight").c_str()), w0, 3, 7, 7, 196, 4, st));
+    // packed conv gradients -> OIHW state_dict gradients (one launch per layer over the cameras: same-named parameters of
+    // consecutive backbones are a constant stride apart in the arena)
+    {
+        const std::string p0 = "backbones.0.0.body.", p1 = "backbones." + std::to_string(C > 1 ? 1 : 0) + ".0.body.";
+        const int64_t cam_stride = ctx->P(p1 + "conv1.weight") - ctx->P(p0 + "conv1.weight");
+        CHK(launch_unpack_wgrad(T.conv1_gw, GP((p0 + "conv1.weight").c_str()), w0, 3, 7, 7, 196, 4, st, C, (int64_t)w0 * 196, cam_stride));
         for (size_t li = 0; li < ctx->convs.size(); ++li) {
             const ConvLayer& cl = ctx->convs[li];
-            CHK(launch_unpack_wgrad(T.conv_gw[li] + (int64_t)cam * cl.cout * cl.K, GP((p + cl.name + ".weight").c_str()), cl.cout,
-                                    cl.cin, cl.k, cl.k, cl.K, cl.cin, st));
+            CHK(launch_unpack_wgrad(T.conv_gw[li], GP((p0 + cl.name + ".weight").c_str()), cl.cout, cl.cin, cl.k, cl.k, cl.K, cl.cin, st,
+                                    C, (int64_t)cl.cout * cl.K, cam_stride));
         }
     }
 
@@ -1064,5 +1066,5 @@ int train_adamw_step(actmi_ctx* ctx, float lr, float lr_backbone, float wd, floa
     if (!ctx->train) { ctx->err = "handle was created without enable_training"; return ACTMI_E_STATE; }
     TrainState& T = *ctx->train;
     CHK(launch_adamw(ctx->pbase, T.gbase, T.mbase, T.vbase, T.group, ctx->ptotal, lr, lr_backbone, wd, b1, b2, eps, step, st));
-    return engine_prepare_weights(ctx, st);       // conv repack, decoder constants, learned pos rows follow the new weights
+    return engine_prepare_weights(ctx, st, true); // conv repack, decoder constants, learned pos rows follow the new weights
 }
