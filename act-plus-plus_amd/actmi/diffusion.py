@@ -106,7 +106,7 @@ class DiffusionNet:
     """Weights prepared once (OHWI convolution weights, unfolded Conv1d matrices, per-camera stacks) + the inference graph."""
 
     def __init__(self, camera_names, action_dim=16, state_dim=14, prediction_horizon=32, num_inference_timesteps=10,
-                 num_train_timesteps=50, device="cuda:0", gemm_prec=None):
+                 num_train_timesteps=50, device="cuda:0", gemm_prec="f16x3"):
         if prediction_horizon % 4:
             raise ValueError("prediction_horizon must be a multiple of 4 (two stride-2 stages of the UNet)")
         if not torch.cuda.is_available():
@@ -116,6 +116,9 @@ class DiffusionNet:
         if num_train_timesteps % num_inference_timesteps:
             raise ValueError("num_inference_timesteps must divide the scheduler's num_train_timesteps")
         self.dev, self.prec = torch.device(device), gemm_prec
+        # f16x3 (fp32 products from exactly split fp16 pieces): weights of 1e-2 magnitude get a 2^8 pre-scale so that
+        # their lo pieces stay normal fp16 numbers; gemm_prec="f32" runs the native fp32 matrix instruction
+        self.bs = 256.0 if gemm_prec == "f16x3" else 0.0
         self.spec = diffusion_state_dict_spec(self.cams, action_dim, state_dim)
         self.ac = _alphas_cumprod(num_train_timesteps)
         self.w = None
@@ -189,12 +192,12 @@ class DiffusionNet:
         """GroupNorm(C // 16) per camera (each camera has its own gain / bias) on [cam][B][H][W][C]."""
         out = torch.empty_like(x)
         for c in range(x.shape[0]):
-            out[c] = ops.groupnorm(x[c], gn[0][c], gn[1][c], x.shape[-1] // 16, act="relu" if relu else None,
-                                   res=None if res is None else res[c])
+            ops.groupnorm(x[c], gn[0][c], gn[1][c], x.shape[-1] // 16, act="relu" if relu else None,
+                          res=None if res is None else res[c], out=out[c])
         return out
 
     def _conv(self, x, w, stride, pad):
-        return ops.conv2d_nhwc(x, w, stride=stride, pad=pad, prec=self.prec)
+        return ops.conv2d_nhwc(x, w, stride=stride, pad=pad, prec=self.prec, b_scale=self.bs)
 
     def obs_cond(self, qpos, image_u8):
         w = self.w
@@ -215,11 +218,11 @@ class DiffusionNet:
                     idt = self._gn_maps(self._conv(x, blk["ds"], s, 0), blk["gd"], relu=False)
                 x = self._gn_maps(y, blk["g2"], res=idt)                   # relu(gn(conv2) + identity)
         ncam, B, H, Wd, _ = x.shape
-        lg = ops.conv2d_nhwc(x, w["kp"], bias=w["kp_b"], stride=1, pad=0, prec=self.prec)          # [cam][B][H][W][K]
+        lg = ops.conv2d_nhwc(x, w["kp"], bias=w["kp_b"], stride=1, pad=0, prec=self.prec, b_scale=self.bs)          # [cam][B][H][W][K]
         feats = []
         for c in range(ncam):
             kp = ops.spatial_softmax(lg[c].reshape(B, H * Wd, -1), H, Wd)                           # [B][K][2]
-            feats.append(ops.gemm(kp.reshape(B, -1), w["lin"][c][0], bias=w["lin"][c][1], prec=self.prec))
+            feats.append(ops.gemm(kp.reshape(B, -1), w["lin"][c][0], bias=w["lin"][c][1], prec=self.prec, b_scale=self.bs))
         return torch.cat(feats + [qpos.to(torch.float32)], dim=1).contiguous()
 
     def _conv1d(self, x, wk, bk, k, stride=1, pad=None, transposed=False):
@@ -227,14 +230,14 @@ class DiffusionNet:
         pad = k // 2 if pad is None else pad
         cols = ops.unfold1d(x, k, stride, pad, transposed)
         To = cols.shape[1]
-        y = ops.gemm(cols.reshape(B * To, k * Cc), self.w[wk], bias=self.w[bk], prec=self.prec)
+        y = ops.gemm(cols.reshape(B * To, k * Cc), self.w[wk], bias=self.w[bk], prec=self.prec, b_scale=self.bs)
         return y.reshape(B, To, -1)
 
     def _crb(self, p, x, gm, k=5):
         w = self.w
         B = x.shape[0]
         y = self._conv1d(x, p + "blocks.0.block.0.weight", p + "blocks.0.block.0.bias", k)
-        emb = ops.gemm(gm, w[p + "cond_encoder.1.weight"], bias=w[p + "cond_encoder.1.bias"], prec=self.prec)     # [B][2*out]
+        emb = ops.gemm(gm, w[p + "cond_encoder.1.weight"], bias=w[p + "cond_encoder.1.bias"], prec=self.prec, b_scale=self.bs)     # [B][2*out]
         oc = y.shape[-1]
         y = ops.groupnorm(y, w[p + "blocks.0.block.1.weight"], w[p + "blocks.0.block.1.bias"], 8, act="mish",
                           film=(emb[:, :oc], emb[:, oc:]))
@@ -252,8 +255,8 @@ class DiffusionNet:
         e = np.exp(np.arange(half, dtype=np.float32) * np.float32(-(math.log(10000) / (half - 1))))
         arg = np.float32(timestep) * e
         emb = torch.from_numpy(np.concatenate([np.sin(arg), np.cos(arg)]).astype(np.float32)).to(self.dev).repeat(B, 1)
-        g = ops.gemm(emb, w["diffusion_step_encoder.1.weight"], bias=w["diffusion_step_encoder.1.bias"], prec=self.prec)
-        g = ops.gemm(ops.mish(g), w["diffusion_step_encoder.3.weight"], bias=w["diffusion_step_encoder.3.bias"], prec=self.prec)
+        g = ops.gemm(emb, w["diffusion_step_encoder.1.weight"], bias=w["diffusion_step_encoder.1.bias"], prec=self.prec, b_scale=self.bs)
+        g = ops.gemm(ops.mish(g), w["diffusion_step_encoder.3.weight"], bias=w["diffusion_step_encoder.3.bias"], prec=self.prec, b_scale=self.bs)
         gm = ops.mish(torch.cat([g, cond], dim=1).contiguous())            # every cond_encoder starts with the same Mish
         if gm.shape[1] % 4:
             gm = torch.nn.functional.pad(gm, (0, 4 - gm.shape[1] % 4)).contiguous()      # matches the zero-padded weight columns

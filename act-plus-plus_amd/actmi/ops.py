@@ -171,13 +171,13 @@ def gemm16(A16, W16, alpha=1.0, bias=None, scale=None, res=None, res_fmt="s16", 
     return out
 
 
-def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1, pad=1, prec=None, w_split=False):
+def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1, pad=1, prec=None, w_split=False, b_scale=0.0):
     """x [G,B,H,W,Cin] camera-major NHWC; w_ohwi [G,Cout,KH,KW,Cin]; scale/bias [G,Cout]; returns [G,B,Ho,Wo,Cout]."""
     lib = L.load()
     G, B, H, W, Cin = x.shape
     _, Cout, KH, KW, _ = w_ohwi.shape
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-    out = torch.zeros((G, B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    out = torch.empty((G, B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)     # every element is written (no split-K here)
     d = L.GemmDesc()
     d.A, d.mode = x.data_ptr(), 1
     d.H, d.W, d.Cin, d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo = H, W, Cin, KH, KW, stride, pad, Ho, Wo
@@ -192,7 +192,8 @@ def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1
     d.M, d.N, d.K, d.groups = B * Ho * Wo, Cout, KH * KW * Cin, G
     d.gA, d.gB, d.gSB = B * H * W * Cin, Cout * KH * KW * Cin, Cout
     d.gC = d.gRes = B * Ho * Wo * Cout
-    d.prec, d.b_split, d.b_scale = PREC[prec], 1 if w_split else 0, float(w_split)
+    # f16x3: w_split = scale of a pre-split weight image; b_scale = power-of-two scale applied to plain fp32 weights on the fly
+    d.prec, d.b_split, d.b_scale = PREC[prec], 1 if w_split else 0, float(w_split) if w_split else float(b_scale)
     L.check(lib.actmi_op_gemm(C.byref(d), L.current_stream_ptr()), None, "op_gemm(conv)")
     return out
 
@@ -322,19 +323,28 @@ def conv1(image, w_oihw, scale, bias, prec=None):
 ACT = {None: 0, "none": 0, "relu": 1, "mish": 2}
 
 
-def groupnorm(x, weight, bias, groups, eps=1e-5, act=None, res=None, res_after=False, film=None):
+_GN_WS = {}
+
+
+def groupnorm(x, weight, bias, groups, eps=1e-5, act=None, res=None, res_after=False, film=None, out=None):
     """x [n, P, C] (any leading spatial shape flattened into P is fine: pass [n, ..., C]); torch.nn.GroupNorm statistics.
-    out = act(GN(x) + res) (res_after=False) or act(GN(x)) * film_scale + film_bias + res (res_after=True)."""
+    out = act(GN(x) + res) (res_after=False) or act(GN(x)) * film_scale + film_bias + res (res_after=True).
+    `out`: optional contiguous tensor of x's shape to write into."""
     lib = L.load()
     x = x.contiguous()
     n, Cc = x.shape[0], x.shape[-1]
     P = x.numel() // (n * Cc)
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.is_contiguous() and out.shape == x.shape
     fs, fb = (film[0].contiguous(), film[1].contiguous()) if film is not None else (None, None)
     rm = 0 if res is None else (2 if res_after else 1)
+    ws = _GN_WS.get(x.device)                 # chunk statistics of the large-map path (3 floats per sample, group, chunk)
+    if ws is None:
+        ws = _GN_WS[x.device] = torch.empty(1 << 20, dtype=torch.float32, device=x.device)
     L.check(lib.actmi_op_groupnorm(_p(x), _p(res.contiguous() if res is not None else None), _p(fs), _p(fb), _p(weight), _p(bias),
-                                   _p(out), n, P, Cc, int(groups), float(eps), ACT[act], rm, L.current_stream_ptr()), None,
-            "op_groupnorm")
+                                   _p(out), n, P, Cc, int(groups), float(eps), ACT[act], rm, _p(ws), ws.numel(),
+                                   L.current_stream_ptr()), None, "op_groupnorm")
     return out
 
 

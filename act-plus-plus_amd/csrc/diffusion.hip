@@ -78,6 +78,88 @@ __global__ __launch_bounds__(256) void groupnorm_kernel(const float* __restrict_
     }
 }
 
+// ---- the same for LARGE maps (the ResNet trunk: 32 samples x 4 groups would be 128 workgroups striding over a million values
+//      each).  Pass 1: workgroup (chunk, sample x group) takes a range of pixels and leaves (count, mean, M2) of its values
+//      (mean first, then squared deviations from it: the chunk is read twice, the second time from L2); pass 2: every thread
+//      combines its (sample, group)'s chunk statistics in chunk order (Chan's parallel-variance update: no cancellation, the
+//      same result in every thread) and normalises 16-byte pieces.  cg % 4 == 0.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ ws, int P, int C, int G,
+                                                       int nch) {
+    const int ng = blockIdx.y, n = ng / G, g = ng - n * G, ch = blockIdx.x;
+    const int cg = C / G, cg4 = cg >> 2;
+    const int p0 = (int)((int64_t)P * ch / nch), p1 = (int)((int64_t)P * (ch + 1) / nch);
+    const float* xb = x + (int64_t)n * P * C + (int64_t)g * cg;
+    const int tot4 = (p1 - p0) * cg4;
+    __shared__ float s_red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < tot4; i += 256) {
+        const int px = i / cg4, c4 = i - px * cg4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (int64_t)(p0 + px) * C + c4 * 4);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    s = wave_sum_f(s);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float cnt = (float)(tot4 * 4);
+    const float mean = cnt > 0.f ? ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / cnt : 0.f;
+    __syncthreads();
+    float q = 0.f;
+    for (int i = threadIdx.x; i < tot4; i += 256) {
+        const int px = i / cg4, c4 = i - px * cg4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (int64_t)(p0 + px) * C + c4 * 4) - mean;
+        q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    q = wave_sum_f(q);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = ws + ((int64_t)ng * nch + ch) * 3;
+        o[0] = cnt; o[1] = mean; o[2] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                       const float* __restrict__ fs, const float* __restrict__ fb,
+                                                       const float* __restrict__ w, const float* __restrict__ b,
+                                                       float* __restrict__ out, const float* __restrict__ ws, int P, int C, int G,
+                                                       int nch, float eps, int act, int res_mode) {
+    // blockIdx.y = sample x group; blockIdx.x strides over the (pixel, 4-channel piece) pairs of that group
+    const int ng = blockIdx.y, n = ng / G, g = ng - n * G;
+    const int cg = C / G, cg4 = cg >> 2;
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    for (int ch = 0; ch < nch; ++ch) {
+        const float* o = ws + ((int64_t)ng * nch + ch) * 3;
+        const float cb = o[0], mb = o[1], qb = o[2];
+        if (cb > 0.f) {
+            const float ct = cnt + cb, d = mb - mean;
+            mean += d * (cb / ct);
+            m2 += qb + d * d * (cnt * cb / ct);
+            cnt = ct;
+        }
+    }
+    const float rstd = 1.f / sqrtf(m2 / cnt + eps);
+    const int64_t base = (int64_t)n * P * C + (int64_t)g * cg;
+    const unsigned tot4 = (unsigned)P * cg4;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < tot4; i += gridDim.x * 256u) {
+        const unsigned px = i / cg4, c4 = i - px * cg4;
+        const int c = g * cg + (int)c4 * 4;
+        const int64_t o = base + (int64_t)px * C + c4 * 4;
+        f32x4 v = (*reinterpret_cast<const f32x4*>(x + o) - mean) * rstd * *reinterpret_cast<const f32x4*>(w + c) +
+                  *reinterpret_cast<const f32x4*>(b + c);
+        if (res_mode == 1) v += *reinterpret_cast<const f32x4*>(res + o);
+        if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = mishf(v[e]);
+        }
+        if (fs) v = v * *reinterpret_cast<const f32x4*>(fs + (int64_t)n * C + c) + *reinterpret_cast<const f32x4*>(fb + (int64_t)n * C + c);
+        if (res_mode == 2) v += *reinterpret_cast<const f32x4*>(res + o);
+        *reinterpret_cast<f32x4*>(out + o) = v;
+    }
+}
+
 // logits [n][P][K] (channel-last output of the 1x1 keypoint convolution), one wave per (sample, keypoint)
 __global__ __launch_bounds__(64) void spatial_softmax_kernel(const float* __restrict__ logits, float* __restrict__ out, int H, int W,
                                                              int K, float inv_temp) {
@@ -166,11 +248,32 @@ int done() { return hipGetLastError() == hipSuccess ? 0 : ACTMI_E_LAUNCH; }
 extern "C" {
 
 int actmi_op_groupnorm(const float* x, const float* res, const float* film_scale, const float* film_bias, const float* w,
-                       const float* b, float* out, int n, int P, int C, int G, float eps, int act, int res_mode, void* stream) {
+                       const float* b, float* out, int n, int P, int C, int G, float eps, int act, int res_mode, float* ws,
+                       int64_t ws_floats, void* stream) {
     if (!x || !w || !b || !out || n < 1 || P < 1 || C < 1 || G < 1 || C % G || act < 0 || act > 2 || res_mode < 0 || res_mode > 2 ||
         (res_mode && !res) || (!film_scale != !film_bias))
         return ACTMI_E_INVALID;
     prof_begin("groupnorm_kernel", 0.0, 4.0 * n * (double)P * C * (res ? 5.0 : 4.0), S(stream));
+    const int cg = C / G;
+    const int64_t per = (int64_t)P * cg;
+    // large maps: chunked statistics + a vectorised apply pass (needs the workspace: 3 floats per sample, group and chunk)
+    if (ws && per >= 16384 && (cg & 3) == 0 && (C & 3) == 0 && per / 4 < ((int64_t)1 << 31) && (int64_t)n * G <= 65535 &&
+        !(((uintptr_t)x | (uintptr_t)out | (uintptr_t)w | (uintptr_t)b | (uintptr_t)res | (uintptr_t)film_scale | (uintptr_t)film_bias) & 15)) {
+        int nch = (int)(per / 16384);                      // ~16k values per chunk
+        const int64_t want = 2048 / ((int64_t)n * G) + 1;  // ... but no more chunks than fill the chip a few times over
+        if (nch > want) nch = (int)want;
+        if (nch > 256) nch = 256;
+        if (nch < 1) nch = 1;
+        if ((int64_t)n * G * nch * 3 <= ws_floats) {
+            hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, n * G), dim3(256), 0, S(stream), x, ws, P, C, G, nch);
+            int bx = (int)((per / 4 + 256 * 8 - 1) / (256 * 8));
+            if (bx > 64) bx = 64;
+            hipLaunchKernelGGL(gn_apply_kernel, dim3(bx, n * G), dim3(256), 0, S(stream), x, res, film_scale, film_bias, w, b, out, ws, P,
+                               C, G, nch, eps, act, res_mode);
+            prof_end(S(stream));
+            return done();
+        }
+    }
     hipLaunchKernelGGL(groupnorm_kernel, dim3((unsigned)(n * G)), dim3(256), 0, S(stream), x, res, film_scale, film_bias, w, b, out, P,
                        C, G, eps, act, res_mode);
     prof_end(S(stream));

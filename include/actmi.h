@@ -344,7 +344,8 @@ int actmi_op_wgrad3x3_c64(const float* dy, const float* x, float* dw, float* ws,
  * ddim_step: in place x <- sqrt_aprev * clamp((x - sqrt_1m_at * eps) * inv_sqrt_at, -1, 1) + sqrt_1m_aprev * eps
  * u8_to_nhwc4: u8 [B][Cam][H][W][3] -> f32 [Cam][B][H][W][4] = v / 255 (fourth channel 0) */
 int actmi_op_groupnorm(const float* x, const float* res, const float* film_scale, const float* film_bias, const float* w,
-                       const float* b, float* out, int n, int P, int C, int G, float eps, int act, int res_mode, void* stream);
+                       const float* b, float* out, int n, int P, int C, int G, float eps, int act, int res_mode, float* ws,
+                       int64_t ws_floats, void* stream);
 int actmi_op_spatial_softmax(const float* logits, float* out, int n, int H, int W, int K, float temperature, void* stream);
 int actmi_op_unfold1d(const float* x, float* out, int B, int T, int C, int k, int stride, int pad, int To, int transposed,
                       void* stream);

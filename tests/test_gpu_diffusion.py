@@ -36,6 +36,24 @@ def test_groupnorm_forms(act):
     assert rel(got, exp) < 2e-6
 
 
+@pytest.mark.parametrize("n,H,W,C", [(3, 60, 80, 64), (2, 33, 47, 128), (5, 120, 160, 64)])
+def test_groupnorm_large_maps(n, H, W, C):
+    """the chunked-statistics path of the ResNet trunk's maps (>= 16k values per sample and group): an offset far from zero
+    (no cancellation in the variance), residual + ReLU, written into a caller-provided view; bitwise repeatable."""
+    g = torch.Generator().manual_seed(n + H)
+    G = C // 16
+    x = torch.randn(n, H, W, C, generator=g) * 2 + 30.0
+    res = torch.randn(n, H, W, C, generator=g)
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    gn = F.group_norm(x.double().permute(0, 3, 1, 2), G, w.double(), b.double(), 1e-5).permute(0, 2, 3, 1)
+    out = torch.empty(2, n, H, W, C, device=D)
+    got = ops.groupnorm(x.to(D), w.to(D), b.to(D), G, act="relu", res=res.to(D), out=out[1])
+    assert got.data_ptr() == out[1].data_ptr()
+    assert rel(got, F.relu(gn + res.double())) < 3e-6
+    assert rel(ops.groupnorm(x.to(D), w.to(D), b.to(D), G), gn) < 3e-6
+    assert torch.equal(got, ops.groupnorm(x.to(D), w.to(D), b.to(D), G, act="relu", res=res.to(D)))
+
+
 def test_spatial_softmax_and_ddim_step_and_mish():
     g = torch.Generator().manual_seed(2)
     n, H, W, K = 2, 15, 20, 32
