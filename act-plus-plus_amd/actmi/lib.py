@@ -130,6 +130,7 @@ def load():
         "actmi_op_maxpool3x3s2": ([vp, vp, i32, i32, i32, i32, vp], i32),
         "actmi_op_conv1": ([vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
         "actmi_op_conv3x3_c64": ([vp, vp, C.c_float, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+        "actmi_op_wgrad7x7s2": ([vp, vp, vp, vp, C.c_int64, vp, i32, i32, i32, i32, vp], i32),
         "actmi_op_wgrad3x3_c64": ([vp, vp, vp, vp, C.c_int64, vp, i32, i32, i32, i32, vp], i32),
         "actmi_op_conv3x3_direct": ([vp, vp, C.c_float, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
         "actmi_op_groupnorm": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp, C.c_int64, vp], i32),

@@ -239,6 +239,21 @@ def wgrad3x3_c64(dy, x, dy_scale=None):
     return dw
 
 
+def wgrad7x7s2(dy, x4, dy_scale=None):
+    """dW [G][64][7][7][4] (O, kh, kw, I) of the stem convolution (7x7 / s2 / p3) from dy [G][B][Ho][Wo][64], x4 [G][B][H][W][4]."""
+    G, B, H, W, Cc = x4.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    assert Cc == 4 and tuple(dy.shape) == (G, B, Ho, Wo, 64)
+    nwg = max(1, min(512 // G, B * ((Wo + 31) // 32)))
+    ws = torch.empty(G * nwg * 64 * 196, device=x4.device, dtype=torch.float32)
+    dw = torch.empty(G, 64, 7, 7, 4, device=x4.device, dtype=torch.float32)
+    lib = L.load()
+    L.check(lib.actmi_op_wgrad7x7s2(_p(dy.contiguous()), _p(x4.contiguous()), _p(dw), _p(ws), ws.numel(),
+                                    _p(dy_scale) if dy_scale is not None else None, G, B, H, W, L.current_stream_ptr()),
+            None, "op_wgrad7x7s2")
+    return dw
+
+
 def conv3x3_direct(x, w_ohwi, scale, bias, res=None, relu=False, w_scale=256.0):
     """direct 3x3 / stride 1 / pad 1 convolution, Cin and Cout multiples of 64 (f16x3): x [G,B,H,W,Cin], w_ohwi [G,Cout,3,3,Cin]."""
     lib = L.load()

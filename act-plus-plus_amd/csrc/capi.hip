@@ -312,6 +312,22 @@ int actmi_op_wgrad3x3_c64(const float* dy, const float* x, float* dw, float* ws,
     return 0;
 }
 
+int actmi_op_wgrad7x7s2(const float* dy, const float* x4, float* dw, float* ws, int64_t ws_floats, const float* dy_scale_dev, int G,
+                        int B, int H, int W, void* stream) {
+    g_op_error.clear();
+    int nwg = 0;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    int rc = launch_wgrad7x7s2(dy, x4, ws, ws_floats, dy_scale_dev, G, B, H, W, Ho, Wo, &nwg, S(stream));
+    if (rc != 0) { g_op_error = "wgrad7x7s2: bad arguments or launch failure"; return rc == -2 ? ACTMI_E_INVALID : ACTMI_E_LAUNCH; }
+    SplitCombineArgs c{};
+    const int64_t slice = (int64_t)64 * 196;
+    c.part = ws; c.nsplit = nwg; c.split_stride = slice; c.gP = slice * nwg; c.ldp = 196;
+    c.C = dw; c.ldc = 196; c.gC = slice; c.M = 64; c.N = 196; c.groups = G;
+    rc = launch_splitk_combine(c, S(stream));
+    if (rc != 0) { g_op_error = "wgrad7x7s2: combine launch failed"; return ACTMI_E_LAUNCH; }
+    return 0;
+}
+
 const char* actmi_op_last_error(void) { return g_op_error.c_str(); }
 
 int actmi_set_gemm_prec(actmi_handle h, int prec) {

@@ -194,6 +194,10 @@ int launch_scale(float* x, int64_t n, float s, hipStream_t st);
 // [groups][*nwg_out][64][576] into ws, to be summed by launch_splitk_combine
 int launch_wgrad3x3_c64(const float* dy, const float* x, float* ws, int64_t ws_floats, const float* dy_scale_dev, int groups, int B,
                         int H, int W, int* nwg_out, hipStream_t st);
+// direct weight gradient of the stem (7x7 / s2 / p3, 4-channel-padded image -> 64 channels; wgrad7.hip): per-workgroup partials
+// [groups][*nwg_out][64][196]
+int launch_wgrad7x7s2(const float* dy, const float* x4, float* ws, int64_t ws_floats, const float* dy_scale_dev, int groups, int B,
+                      int H, int W, int Ho, int Wo, int* nwg_out, hipStream_t st);
 int launch_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, hipStream_t st);
 int launch_pow2_from_bits(float* out, hipStream_t st);      // the scale from bits a producing kernel left in out[1]
 int launch_split16(const float* src, float* dst, int64_t nfloats, float scale, hipStream_t st, uint32_t* flag = nullptr);

@@ -1000,6 +1000,23 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
     // (ReLU + FrozenBN backward of the stem and the operand-scale maximum ride on the pool's backward: one pass over the map)
     CHK(launch_maxpool_bwd_idx(T.pool_arg, gcur, T.g_act1, C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st, ctx->act1,
                                ctx->conv1_scale, B, amax_pre(ctx, T.g_act1, st)));
+    static const bool stem_direct = !(getenv("ACTMI_WGRAD_DIRECT") && getenv("ACTMI_WGRAD_DIRECT")[0] == '0');
+    if (stem_direct && ctx->gemm_prec == ACTMI_PREC_F16X3 && w0 == 64 && T.det_ws && ctx->H1 == (g.image_h - 1) / 2 + 1 &&
+        ctx->W1 == (g.image_w - 1) / 2 + 1 && T.det_ws_floats >= (int64_t)C * 64 * 196) {
+        // the direct kernel (wgrad7.hip) + fixed-order sum of its per-workgroup partials into the packed gradient
+        const float* sc = dyn_scale(ctx, T.g_act1, w0, C * B * ctx->H1 * ctx->W1, w0, st);
+        int nwg = 0;
+        if (launch_wgrad7x7s2(T.g_act1, T.xn4, T.det_ws, T.det_ws_floats, sc, C, B, g.image_h, g.image_w, ctx->H1, ctx->W1, &nwg, st) != 0) {
+            ctx->err = "wgrad7x7s2 launch failed";
+            return ACTMI_E_LAUNCH;
+        }
+        SplitCombineArgs c{};
+        const int64_t slice = (int64_t)64 * 196;
+        c.part = T.det_ws; c.nsplit = nwg; c.split_stride = slice; c.gP = slice * nwg; c.ldp = 196;
+        c.res = T.conv1_gw; c.ldres = 196; c.gRes = slice;
+        c.C = T.conv1_gw; c.ldc = 196; c.gC = slice; c.M = 64; c.N = 196; c.groups = C;
+        if (launch_splitk_combine(c, st) != 0) { ctx->err = "splitk combine launch failed"; return ACTMI_E_LAUNCH; }
+    } else
     {
         GemmArgs a = G0();
         a.A = T.g_act1; a.lda = w0; a.ta = 1; a.M = w0; a.K = B * ctx->H1 * ctx->W1;

@@ -332,6 +332,12 @@ int actmi_op_conv3x3_direct(const float* x, const float* w16, float w_scale, con
 int actmi_op_wgrad3x3_c64(const float* dy, const float* x, float* dw, float* ws, int64_t ws_floats, const float* dy_scale_dev, int G,
                           int B, int H, int W, void* stream);
 
+/* weight gradient of the ResNet stem (7x7 / s2 / p3 convolution of the 4-channel-padded image to 64 channels; training path):
+ * dw[G][64][(r,s,c) = 196] from dy[G][B][Ho][Wo][64] and x4[G][B][H][W][4], Ho = (H-1)/2 + 1, Wo = (W-1)/2 + 1; ws: >= G * 64 *
+ * 196 * min(512 / G, B * ceil(Wo/32)) floats of per-workgroup partials (fixed-order sum); dy_scale_dev as above */
+int actmi_op_wgrad7x7s2(const float* dy, const float* x4, float* dw, float* ws, int64_t ws_floats, const float* dy_scale_dev, int G,
+                        int B, int H, int W, void* stream);
+
 /* ---- DiffusionPolicy inference path (reference policy.py:20-241, imitate_episodes.py:100-118,420-426).
  * The non-GEMM pieces of what the reference delegates to robomimic (ResNet18Conv with BatchNorm -> GroupNorm, SpatialSoftmax,
  * ConditionalUnet1D) and diffusers (DDIMScheduler.step); restated from the published definitions, parity unpinned (neither

@@ -377,3 +377,23 @@ def test_wgrad3x3_c64_matches_torch(G, B, H, W):
         assert rel_err(got[c], exp) < 2e-6
     assert torch.equal(got_s, got * 2.0 ** -20)
     assert torch.equal(got, ops.wgrad3x3_c64(dy.to(dev()), x.to(dev())).cpu())
+
+
+@pytest.mark.parametrize("G,B,H,W", [(1, 1, 12, 64), (2, 2, 30, 46), (4, 1, 64, 96), (1, 3, 9, 130), (2, 1, 2, 2)])
+def test_wgrad7x7s2_matches_torch(G, B, H, W):
+    """weight gradient of the stem (7x7 / s2 / p3 on the 4-channel-padded image) on the direct kernel (strip walk, image rows
+    staged as transposed im2col slices, nine-slot ring) vs torch.nn.grad.conv2d_weight in fp64: widths below / across the
+    32-pixel strip, odd sizes, a 1x1 output map; device-side operand scale; bitwise repeatable."""
+    g = torch.Generator().manual_seed(G * 10 + H + W)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = torch.randn(G, B, H, W, 4, generator=g)
+    dy = torch.randn(G, B, Ho, Wo, 64, generator=g)
+    got = ops.wgrad7x7s2(dy.to(dev()), x.to(dev())).cpu()
+    sc = torch.tensor([2.0 ** 20], device=dev())
+    got_s = ops.wgrad7x7s2(dy.to(dev()) * 2.0 ** -20, x.to(dev()), dy_scale=sc).cpu()
+    for c in range(G):
+        exp = torch.nn.grad.conv2d_weight(x[c].permute(0, 3, 1, 2).double(), (64, 4, 7, 7), dy[c].permute(0, 3, 1, 2).double(),
+                                          stride=2, padding=3).permute(0, 2, 3, 1)          # [O][kh][kw][I]
+        assert rel_err(got[c], exp) < 2e-6
+    assert torch.equal(got_s, got * 2.0 ** -20)
+    assert torch.equal(got, ops.wgrad7x7s2(dy.to(dev()), x.to(dev())).cpu())
