@@ -122,7 +122,7 @@ int launch_maxpool_bwd_idx(const uint8_t* arg, const float* dy, float* dx, int n
 // y = LN(x + res[m % res_mod]) * w + b ; optional second LN (w2,b2) applied on top.
 int launch_layernorm(const float* x, const float* res, int res_mod, const float* w, const float* b,
                      const float* w2, const float* b2, float* y, int M, int D, float eps, hipStream_t st,
-                     std::string* err);
+                     std::string* err, int nsplit = 1, int64_t split_stride = 0, const float* bias = nullptr);
 
 // ---- attention (attn.hip) -----------------------------------------------------------------------
 typedef actmi_attn_desc AttnArgs;

@@ -157,7 +157,15 @@ struct actmi_ctx {
 
 int engine_create(const actmi_config* cfg, actmi_ctx** out);
 // forward GEMMs of a handle go through here: applies the handle's precision and swaps in pre-split weights
-int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half = -1);
+// LayerNorm that follows a product (y = LN(C), optionally a second LN on top): when the product's contraction is split, the
+// LayerNorm kernel sums the slices itself (no combine pass); done tells the caller whether that happened
+struct LnFuse {
+    const float *w, *b, *w2, *b2;
+    float* out;
+    float eps;
+    bool done;
+};
+int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half = -1, LnFuse* ln = nullptr);
 int engine_destroy(actmi_ctx* ctx);
 const char* engine_create_error();
 int engine_finalize(actmi_ctx* ctx, hipStream_t st);

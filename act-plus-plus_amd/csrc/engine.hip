@@ -153,7 +153,8 @@ int dev_alloc(actmi_ctx* ctx, float** p, int64_t nfloats) {
 
 }  // namespace
 
-int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half) {
+int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half, LnFuse* ln) {
+    if (ln) ln->done = false;
     a.prec = ctx->gemm_prec;
     // ws_half 0 / 1: this launch belongs to one of two concurrent branches, each with its own half of the slice workspace
     const int64_t ws_part = (ctx->splitk_ws_floats / ctx->nbranch) & ~(int64_t)3;
@@ -202,6 +203,13 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half) {
             p.split_stride = slice;
             int rc = launch_gemm(p, st, &ctx->err);
             if (rc) return rc;
+            if (ln && groups == 1 && !a.scale && !a.relu && (!a.res || a.ldres == a.N)) {
+                // the LayerNorm that follows reads the slices itself: sum in slice order + bias + residual, as the combine does
+                rc = launch_layernorm(ws, a.res, 0, ln->w, ln->b, ln->w2, ln->b2, ln->out, a.M, a.N, ln->eps, st, &ctx->err, S, slice,
+                                      a.bias);
+                ln->done = rc == 0;
+                return rc;
+            }
             SplitCombineArgs c{};
             c.part = ws; c.nsplit = S; c.split_stride = slice; c.gP = slice * S; c.ldp = a.N;
             c.scale = a.scale; c.bias = a.bias; c.gSB = a.gSB;
@@ -859,8 +867,9 @@ int engine_encoder_layer(actmi_ctx* ctx, const EncW& w, const TView& V, const fl
     CHK(ctx_gemm(ctx, f1, st, V.half));
     GemmArgs f2 = linear_args(V.Hb, F, M, F, w.l2w, D, w.l2b, V.Y, D);
     f2.res = V.X1; f2.ldres = D;
-    CHK(ctx_gemm(ctx, f2, st, V.half));
-    CHK(launch_layernorm(V.Y, nullptr, 0, w.n2w, w.n2b, nullptr, nullptr, x, M, D, 1e-5f, st, &ctx->err));
+    LnFuse ln2{w.n2w, w.n2b, nullptr, nullptr, x, 1e-5f, false};
+    CHK(ctx_gemm(ctx, f2, st, V.half, &ln2));
+    if (!ln2.done) CHK(launch_layernorm(V.Y, nullptr, 0, w.n2w, w.n2b, nullptr, nullptr, x, M, D, 1e-5f, st, &ctx->err));
     return 0;
 }
 
@@ -893,9 +902,11 @@ int engine_decoder_infer(actmi_ctx* ctx, const TView& V, int B, float* a_hat, hi
     CHK(ctx_gemm(ctx, f1, st, V.half));
     GemmArgs f2 = linear_args(V.dH, F, M, F, d.l2w, D, d.l2b, V.dY, D);
     f2.res = V.dT2; f2.ldres = D;
-    CHK(ctx_gemm(ctx, f2, st, V.half));
-    CHK(launch_layernorm(V.dY, nullptr, 0, d.n3w, d.n3b, ctx->P("transformer.decoder.norm.weight"),
-                         ctx->P("transformer.decoder.norm.bias"), V.hs, M, D, 1e-5f, st, &ctx->err));
+    LnFuse ln3{d.n3w, d.n3b, ctx->P("transformer.decoder.norm.weight"), ctx->P("transformer.decoder.norm.bias"), V.hs, 1e-5f, false};
+    CHK(ctx_gemm(ctx, f2, st, V.half, &ln3));
+    if (!ln3.done)
+        CHK(launch_layernorm(V.dY, nullptr, 0, d.n3w, d.n3b, ctx->P("transformer.decoder.norm.weight"),
+                             ctx->P("transformer.decoder.norm.bias"), V.hs, M, D, 1e-5f, st, &ctx->err));
     GemmArgs ah = linear_args(V.hs, D, M, D, ctx->P("action_head.weight"), g.action_dim, ctx->P("action_head.bias"),
                               a_hat, g.action_dim);
     // default-on output guard: an operand that left the fp16 range of the f16x3 products surfaces as inf / NaN in a_hat;

@@ -18,7 +18,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         int res_mod, const float* __restrict__ w,
                                                         const float* __restrict__ b, const float* __restrict__ w2,
                                                         const float* __restrict__ b2, float* __restrict__ y, int M,
-                                                        int D, float eps) {
+                                                        int D, float eps, int nsplit, int64_t split_stride,
+                                                        const float* __restrict__ bias) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -32,6 +33,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int c = lane + 64 * i;
         if (c < D4) {
             f32x4 t = xr[c];
+            // x given as nsplit split-K slices (ctx_gemm): summed in slice order, then + bias, then + res -- the sequence of
+            // splitk_combine_kernel, so the fused form gives the same bits as combine + layernorm
+            for (int sidx = 1; sidx < nsplit; ++sidx) t += xr[(int64_t)sidx * (split_stride >> 2) + c];
+            if (bias) t += reinterpret_cast<const f32x4*>(bias)[c];
             if (rr) t += rr[c];
             v[i] = t;
             s += (t[0] + t[1]) + (t[2] + t[3]);
@@ -88,12 +93,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }  // namespace
 
 int launch_layernorm(const float* x, const float* res, int res_mod, const float* w, const float* b, const float* w2,
-                     const float* b2, float* y, int M, int D, float eps, hipStream_t st, std::string* err) {
+                     const float* b2, float* y, int M, int D, float eps, hipStream_t st, std::string* err, int nsplit,
+                     int64_t split_stride, const float* bias) {
     if ((D & 3) || D > 64 * 4 * MAXV) { if (err) *err = "layernorm: D must be a multiple of 4 and <= 2048"; return -2; }
+    if (nsplit > 1 && (split_stride & 3)) { if (err) *err = "layernorm: slice stride must be a multiple of 4"; return -2; }
     if (M <= 0) return 0;
     prof_begin("layernorm_kernel", 0.0, 4.0 * M * D * (res && !res_mod ? 3.0 : 2.0), st);
     const int nv = (D / 4 + 63) / 64;
-#define ACTMI_LN(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, dim3((M + 3) / 4), dim3(256), 0, st, x, res, res_mod, w, b, w2, b2, y, M, D, eps)
+#define ACTMI_LN(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, dim3((M + 3) / 4), dim3(256), 0, st, x, res, res_mod, w, b, w2, b2, y, M, D, eps, nsplit, split_stride, bias)
     switch (nv) {
         case 1: ACTMI_LN(1); break;
         case 2: ACTMI_LN(2); break;
