@@ -125,6 +125,8 @@ struct actmi_ctx {
     hipEvent_t ev_pjoins[3] = {nullptr, nullptr, nullptr};
     int nbranch = 2;                   // ACTMI_BRANCHES (2 .. 4)
     bool cam_pipe = false;
+    int ln_split_short = 1;            // the same for 16 <= K/32 < 64 (out-proj: K = 512) (ACTMI_LN_SPLIT_SHORT)
+    int ln_split = 3;                  // split factor of a long-K product followed by a slice-summing LayerNorm (ACTMI_LN_SPLIT)
     int last_B = 0;                    // batch of the forward in flight (debug views)
     int policy_mult = 1;               // split-K policy counts the tiles of the WHOLE camera set while a half is being launched
     bool conv_direct = false;          // layer2-4 stride-1 3x3 convolutions on the direct kernel (conv3g.hip): measured slower, opt-in

@@ -188,6 +188,10 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half, LnFuse* ln
         // 167 us + a 26 us combine pass split four ways; the K <= 3200 shapes do not pay for their combine pass --
         // profiles/r02_splitk_b8_sweep.json)
         if (S == 1 && tiles < ctx->sk_maxtiles_long && nk >= ctx->sk_long_nk) S = (int)((ctx->sk_target_long + tiles - 1) / tiles);
+        // a product whose LayerNorm sums the slices itself pays no combine pass: a long contraction on a grid that leaves CUs
+        // idle (FFN2: K = 3200 on 304 workgroups at B = 8) is split even where the general rule would not (ACTMI_LN_SPLIT)
+        if (ln && S == 1 && ctx->ln_split > 1 && nk >= 64 && tiles < 2 * ctx->sk_maxtiles) S = ctx->ln_split;
+        if (ln && S == 1 && ctx->ln_split_short > 1 && nk >= 16 && nk < 64 && tiles < 2 * ctx->sk_maxtiles) S = ctx->ln_split_short;
         if (S > 8) S = 8;
         if (S > nk / ctx->sk_minnk) S = nk / ctx->sk_minnk;
         while (S >= 2 && (S - 1) * ((nk + S - 1) / S) >= nk) --S;              // every split must own a K tile
@@ -524,6 +528,8 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
             ctx->err = "cannot create the side stream";
             return fail(ACTMI_E_LAUNCH);
         }
+        if (const char* e8 = getenv("ACTMI_LN_SPLIT")) ctx->ln_split = atoi(e8);
+        if (const char* e9 = getenv("ACTMI_LN_SPLIT_SHORT")) ctx->ln_split_short = atoi(e9);
         const char* e5 = getenv("ACTMI_CAM_PIPE");
         ctx->cam_pipe = !(e5 && e5[0] == '0');             // default on; ACTMI_CAM_PIPE=0: one branch (every launch spans all cameras)
         if (const char* e6 = getenv("ACTMI_BRANCHES")) ctx->nbranch = atoi(e6);
@@ -860,8 +866,9 @@ int engine_encoder_layer(actmi_ctx* ctx, const EncW& w, const TView& V, const fl
     CHK(launch_attention(at, st, &ctx->err));
     GemmArgs op = linear_args(V.ATT, D, M, D, w.attn.out_w, D, w.attn.out_b, V.Y, D);
     op.res = x; op.ldres = D;
-    CHK(ctx_gemm(ctx, op, st, V.half));
-    CHK(launch_layernorm(V.Y, nullptr, 0, w.n1w, w.n1b, nullptr, nullptr, V.X1, M, D, 1e-5f, st, &ctx->err));
+    LnFuse ln1{w.n1w, w.n1b, nullptr, nullptr, V.X1, 1e-5f, false};
+    CHK(ctx_gemm(ctx, op, st, V.half, &ln1));
+    if (!ln1.done) CHK(launch_layernorm(V.Y, nullptr, 0, w.n1w, w.n1b, nullptr, nullptr, V.X1, M, D, 1e-5f, st, &ctx->err));
     GemmArgs f1 = linear_args(V.X1, D, M, D, w.l1w, F, w.l1b, V.Hb, F);
     f1.relu = 1;
     CHK(ctx_gemm(ctx, f1, st, V.half));
