@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args p, int tiles_per_r
     float* s_w = reinterpret_cast<float*>(smem_raw);
     float (*s_patch)[PROWS * PSTRIDE] = reinterpret_cast<float (*)[PROWS * PSTRIDE]>(s_w + 64 * WSTRIDE);
     float* s_lut = &s_patch[0][0] + 2 * PROWS * PSTRIDE;
-    const int cam = blockIdx.y;
+    const int cam = blockIdx.y + p.cam0;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int mtile = wave & 1, ntile = wave >> 1;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void conv1_f16x3_kernel(Conv1Args p, int tiles
     unsigned char* s_wl = s_wh + F_WBYTES;
     unsigned char* s_patch = s_wl + F_WBYTES;                      // two buffers of F_PATCH bytes
     uint32_t* s_lut = reinterpret_cast<uint32_t*>(s_patch + 2 * F_PATCH);
-    const int cam = blockIdx.y;
+    const int cam = blockIdx.y + p.cam0;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int prow = wave >> 1, phalf = wave & 1;
@@ -593,13 +593,14 @@ int launch_conv1(const Conv1Args& a, hipStream_t st, std::string* err) {
         if (a.vpool) {
             if ((a.Ho & 1) || (a.Cout & 3)) { if (err) *err = "conv1: vpool needs an even output height and Cout % 4 == 0"; return -2; }
             const int hpairs = a.Ho / 2;
-            int nseg = blocks_target / (a.C * a.B * tiles_per_row > 0 ? a.C * a.B * tiles_per_row : 1);
+            const int nc_l = a.ncam > 0 ? a.ncam : a.C;
+            int nseg = blocks_target / (nc_l * a.B * tiles_per_row > 0 ? nc_l * a.B * tiles_per_row : 1);
             if (nseg > hpairs / 4) nseg = hpairs / 4;            // chains of >= 4 row pairs (+1 halo step); only B = 1 gets there
             if (nseg < 1) nseg = 1;
             av.vpool_nseg = nseg;
             gx = a.B * tiles_per_row * nseg;
         }
-        dim3 grid(gx, a.C);
+        dim3 grid(gx, a.ncam > 0 ? a.ncam : a.C);
         prof_begin(a.fmt == 0 ? "conv1_f16x3_kernel<0>" : "conv1_f16x3_kernel<1>", 2.0 * a.B * a.C * a.Ho * a.Wo * a.Cout * 147.0,
                    (double)a.B * a.C * ((double)a.H * a.W * 3 * (a.fmt == 0 ? 1 : 4) + 4.0 * a.Ho * a.Wo * a.Cout), st);
         static bool attr16 = false;
@@ -621,7 +622,7 @@ int launch_conv1(const Conv1Args& a, hipStream_t st, std::string* err) {
     // keep tiles-per-block balanced
     const int per = (tiles_per_cam + gx - 1) / gx;
     gx = (tiles_per_cam + per - 1) / per;
-    dim3 grid(gx, a.C);
+    dim3 grid(gx, a.ncam > 0 ? a.ncam : a.C);
     prof_begin(a.fmt == 0 ? "conv1_kernel<0>" : "conv1_kernel<1>", 2.0 * a.B * a.C * a.Ho * a.Wo * a.Cout * 147.0,
                (double)a.B * a.C * ((double)a.H * a.W * 3 * (a.fmt == 0 ? 1 : 4) + 4.0 * a.Ho * a.Wo * a.Cout), st);
     constexpr int smem = (64 * WSTRIDE + 2 * PROWS * PSTRIDE + 3 * 256) * 4;

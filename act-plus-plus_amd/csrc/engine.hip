@@ -687,14 +687,29 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
     c1.wscale = ctx->conv1_wscale;
     // inference never needs conv1's own map: the stem emits the vertical half of the max pool (half the bytes) and a
     // row-wise pass finishes it.  Same maxima, so the result is bit-identical to conv1 -> 3x3 pool.
-    if (ctx->conv1_vpool && ctx->stop_stage != "conv1" && ctx->gemm_prec == ACTMI_PREC_F16X3 && (ctx->H1 & 1) == 0 && (w0 & 3) == 0 && ctx->H2 == ctx->H1 / 2) {
-        c1.vpool = 1;
-        CHK(launch_conv1(c1, st, &ctx->err));
-        CHK(launch_hpool(ctx->act1, ctx->buf[0], C * B * ctx->H2, ctx->W1, w0, ctx->W2, st));
-    } else {
-        CHK(launch_conv1(c1, st, &ctx->err));
-        CHK(launch_maxpool(ctx->act1, ctx->buf[0], C * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, st));
-    }
+    const bool vpool = ctx->conv1_vpool && ctx->stop_stage != "conv1" && ctx->gemm_prec == ACTMI_PREC_F16X3 && (ctx->H1 & 1) == 0 &&
+                       (w0 & 3) == 0 && ctx->H2 == ctx->H1 / 2;
+    // stem (conv1 + pool) of the cameras [c0, c0 + nc) on stream ss
+    auto run_stem = [&](int c0, int nc, hipStream_t ss) -> int {
+        Conv1Args cc = c1;
+        cc.cam0 = c0; cc.ncam = nc;
+        if (vpool) {
+            cc.vpool = 1;
+            CHK(launch_conv1(cc, ss, &ctx->err));
+            const int64_t a_cam = (int64_t)B * ctx->H2 * ctx->W1 * w0, p_cam = (int64_t)B * ctx->H2 * ctx->W2 * w0;
+            CHK(launch_hpool(ctx->act1 + c0 * a_cam, ctx->buf[0] + c0 * p_cam, nc * B * ctx->H2, ctx->W1, w0, ctx->W2, ss));
+        } else {
+            CHK(launch_conv1(cc, ss, &ctx->err));
+            const int64_t a_cam = (int64_t)B * ctx->H1 * ctx->W1 * w0, p_cam = (int64_t)B * ctx->H2 * ctx->W2 * w0;
+            CHK(launch_maxpool(ctx->act1 + c0 * a_cam, ctx->buf[0] + c0 * p_cam, nc * B, ctx->H1, ctx->W1, w0, ctx->H2, ctx->W2, ss));
+        }
+        return 0;
+    };
+    // the stem inside the branches (ACTMI_STEM_BRANCH=1): one branch's conv1 (bound by its own instruction stream) beside the
+    // other's pool / layer1 launches
+    static const bool stem_in_branch = getenv("ACTMI_STEM_BRANCH") && getenv("ACTMI_STEM_BRANCH")[0] == '1';
+    const bool pipe_early = stem_in_branch && ctx->cam_pipe && ctx->pipe_stream && C >= 2 && !prof_enabled() && ctx->stop_stage.empty();
+    if (!pipe_early) CHK(run_stem(0, C, st));
     ctx->dbg.clear();
     ctx->dbg["conv1"] = {ctx->act1, (int64_t)C * B * ctx->H1 * ctx->W1 * w0};
     ctx->dbg["maxpool"] = {ctx->buf[0], (int64_t)C * B * ctx->H2 * ctx->W2 * w0};
@@ -809,7 +824,8 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
             const int c0 = i * C / nb, c1 = (i + 1) * C / nb;
             hipStream_t bs = i ? ctx->pipe_streams[i - 1] : st;
             if (i) HIPCHK(hipStreamWaitEvent(bs, ctx->ev_pfork, 0));
-            rc = run_layers(c0, c1 - c0, bs, i);
+            if (pipe_early) rc = run_stem(c0, c1 - c0, bs);
+            if (rc == 0) rc = run_layers(c0, c1 - c0, bs, i);
             if (i) HIPCHK(hipEventRecord(ctx->ev_pjoins[i - 1], bs));
         }
         for (int i = 1; i < nb; ++i) HIPCHK(hipStreamWaitEvent(st, ctx->ev_pjoins[i - 1], 0));     // join (after branch 0 is queued)
