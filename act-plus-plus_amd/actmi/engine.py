@@ -89,6 +89,9 @@ class ACTEngine:
                     unexpected.append(k)
         if strict and (missing or unexpected):
             raise RuntimeError(f"state_dict mismatch: missing {missing[:5]}... unexpected {unexpected[:5]}...")
+        # actmi_set_param / actmi_get_param copy with blocking hipMemcpy on the null stream, which is not ordered with work in
+        # flight on torch's (non-blocking) streams or the library's branch streams: drain the device first
+        torch.cuda.synchronize(self.device)
         for k, shape in self.spec.items():
             if prefix + k not in sd:
                 continue
@@ -107,6 +110,7 @@ class ACTEngine:
 
     def state_dict(self, prefix: str = "") -> "OrderedDict[str, torch.Tensor]":
         out = OrderedDict()
+        torch.cuda.synchronize(self.device)          # (see load_state_dict: an optimizer step may still be running)
         for k, shape in self.spec.items():
             t = torch.empty(shape, dtype=torch.float32)
             L.check(self.lib.actmi_get_param(self.h, k.encode(), C.c_void_p(t.data_ptr()), t.numel() * 4, 0), self.h,
