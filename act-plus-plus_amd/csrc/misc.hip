@@ -47,31 +47,35 @@ __global__ void repack_conv_w_kernel(const float* __restrict__ in, float* __rest
     out[g * g_out + (int64_t)o * kpad + k] = v;
 }
 
-// Temporal ensembling over E episodes (reference imitate_episodes.py:338-339, 402-411), one wave per episode.
+// Temporal ensembling over E episodes (reference imitate_episodes.py:338-339, 402-411), one 256-thread workgroup per episode.
 // ring[e][slot = t % Q][i][a] holds the chunk predicted at time t; at step t the rows r in [t-Q+1, t] contribute
 // chunk_r[t-r].  A row counts only when ALL its A values are != 0 ("actions_populated"); weights
 // exp(-k*i), i = 0 for the OLDEST populated row, normalised; products and sum in float64 as in the reference
-// (numpy float64 weights promote the float32 actions).
-__global__ __launch_bounds__(64) void ensemble_kernel(float* __restrict__ ring, int* __restrict__ tcount,
-                                                      const float* __restrict__ chunk, double k,
-                                                      double* __restrict__ out, uint8_t* __restrict__ populated,
-                                                      int Q, int A) {
-    // one wave per episode.  LDS: Q doubles (normalised weight of row j, 0 when the row is not populated)
+// (numpy float64 weights promote the float32 actions).  Every sum has a fixed shape (lane / wave / row-class order), so a
+// step is bitwise repeatable.
+__global__ __launch_bounds__(256) void ensemble_kernel(float* __restrict__ ring, int* __restrict__ tcount,
+                                                       const float* __restrict__ chunk, double k,
+                                                       double* __restrict__ out, uint8_t* __restrict__ populated,
+                                                       int Q, int A) {
+    // LDS: Q doubles (normalised weight of row j, 0 when the row is not populated) + fixed scratch
     extern __shared__ __attribute__((aligned(8))) unsigned char s_raw[];
     double* s_w = reinterpret_cast<double*>(s_raw);
-    const int e = blockIdx.x, lane = threadIdx.x;
+    __shared__ int s_cnt[4];
+    __shared__ double s_ws[4];
+    __shared__ double s_acc[256];
+    const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = tcount[e];
     float* rg = ring + (int64_t)e * Q * Q * A;
     const float* ch = chunk + (int64_t)e * Q * A;
     float* slot = rg + (int64_t)(t % Q) * Q * A;
-    for (int i = lane; i < Q * A; i += 64) slot[i] = ch[i];
+    for (int i = tid; i < Q * A; i += 256) slot[i] = ch[i];
     __syncthreads();
     // rows oldest first: j -> r = t-(Q-1)+j; populated = all A values non-zero (imitate_episodes.py:405-406);
     // weight exp(-k*i) with i = rank of the row among the populated ones (:407-409)
     int base = 0;
     double wpart = 0.0;
-    for (int j0 = 0; j0 < Q; j0 += 64) {
-        const int j = j0 + lane;
+    for (int j0 = 0; j0 < Q; j0 += 256) {
+        const int j = j0 + tid;
         const int r = t - (Q - 1) + j;
         bool pop = false;
         if (j < Q && r >= 0) {
@@ -80,35 +84,46 @@ __global__ __launch_bounds__(64) void ensemble_kernel(float* __restrict__ ring, 
             for (int a = 0; a < A; ++a) pop = pop && (row[a] != 0.f);
         }
         const unsigned long long m = __ballot(pop);
-        const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
-        base += __popcll(m);
+        if (lane == 0) s_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += s_cnt[w];
+        const int idx = base + before + __popcll(m & ((1ull << lane) - 1ull));
+        base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
         const double w = pop ? exp(-k * (double)idx) : 0.0;
         if (j < Q) {
             s_w[j] = w;
             if (populated) populated[(int64_t)e * Q + j] = pop ? 1 : 0;
         }
         wpart += w;
+        __syncthreads();                                   // s_cnt is rewritten by the next chunk of rows
     }
-    // fixed-order butterfly: every lane ends with the same sum
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) wpart += __shfl_xor(wpart, o);
+    if (lane == 0) s_ws[wave] = wpart;
     __syncthreads();
-    // lanes (a, g): action component a = lane % 16-or-A-slot, row class g; A <= 64
+    const double wsum = (s_ws[0] + s_ws[1]) + (s_ws[2] + s_ws[3]);
+    // threads (a, g): action component a, row class g (rows j = g mod ng); A <= 64
     const int per = A <= 16 ? 16 : (A <= 32 ? 32 : 64);
-    const int a = lane % per, g = lane / per, ng = 64 / per;
+    const int a = tid % per, g = tid / per, ng = 256 / per;
     double acc = 0.0;
     if (a < A) {
         for (int j = g; j < Q; j += ng) {
             const double w = s_w[j];
             if (w != 0.0) {
                 const int r = t - (Q - 1) + j;
-                acc += (double)rg[((int64_t)(r % Q) * Q + (t - r)) * A + a] * (w / wpart);
+                acc += (double)rg[((int64_t)(r % Q) * Q + (t - r)) * A + a] * (w / wsum);
             }
         }
     }
-    for (int o = per; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
-    if (lane < A) out[(int64_t)e * A + lane] = acc;
-    if (lane == 0) tcount[e] = t + 1;
+    s_acc[tid] = acc;
+    __syncthreads();
+    if (tid < A) {
+        double tot = 0.0;
+        for (int gg = 0; gg < ng; ++gg) tot += s_acc[gg * per + tid];
+        out[(int64_t)e * A + tid] = tot;
+    }
+    if (tid == 0) tcount[e] = t + 1;
 }
 
 // FrozenBatchNorm2d folded to a per-channel affine, reference backbone.py:47-57:
@@ -583,6 +598,6 @@ int launch_ensemble(float* ring, int* tcount, const float* chunk, double k, doub
                     int Q, int A, hipStream_t st) {
     if (E <= 0) return 0;
     if (A > 64) return -2;
-    hipLaunchKernelGGL(ensemble_kernel, dim3(E), dim3(64), Q * sizeof(double), st, ring, tcount, chunk, k, out, populated, Q, A);
+    hipLaunchKernelGGL(ensemble_kernel, dim3(E), dim3(256), Q * sizeof(double), st, ring, tcount, chunk, k, out, populated, Q, A);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
