@@ -35,7 +35,7 @@ class ACTEngine:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = L.load()
-        c = L.ActmiConfig(num_cams=cfg.num_cams, image_h=cfg.image_h, image_w=cfg.image_w, base_width=cfg.base_width,
+        c = L.ActmiConfig(struct_size=C.sizeof(L.ActmiConfig), num_cams=cfg.num_cams, image_h=cfg.image_h, image_w=cfg.image_w, base_width=cfg.base_width,
                           hidden_dim=cfg.hidden_dim, nheads=cfg.nheads, dim_feedforward=cfg.dim_feedforward,
                           enc_layers=cfg.enc_layers, dec_layers=cfg.dec_layers, num_queries=cfg.num_queries,
                           state_dim=cfg.state_dim, action_dim=cfg.action_dim, latent_dim=cfg.latent_dim,

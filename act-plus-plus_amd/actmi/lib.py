@@ -17,7 +17,8 @@ IMG_F32_NCHW = 1
 
 
 class ActmiConfig(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in (
+    # struct_size first: the ABI guard of include/actmi.h (actmi_create rejects a binding whose struct differs)
+    _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_int32) for n in (
         "num_cams", "image_h", "image_w", "base_width", "hidden_dim", "nheads", "dim_feedforward", "enc_layers",
         "dec_layers", "num_queries", "state_dim", "action_dim", "latent_dim", "has_cvae_encoder", "max_batch",
         "enable_training")] + [("kl_weight", C.c_float)] + [(n, C.c_int32) for n in ("vq", "vq_class", "vq_dim")]

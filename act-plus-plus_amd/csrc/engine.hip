@@ -359,6 +359,12 @@ float* actmi_ctx::P(const std::string& key) {
 int engine_create(const actmi_config* cfg, actmi_ctx** out) {
     if (!cfg || !out) { g_create_error = "null argument"; return ACTMI_E_INVALID; }
     const actmi_config& g = *cfg;
+    if (g.struct_size != (uint32_t)sizeof(actmi_config)) {
+        // the first field is readable whatever the caller's struct looks like; nothing else is trusted before this check
+        g_create_error = "actmi_config.struct_size is " + std::to_string(g.struct_size) + ", this library expects " +
+                         std::to_string(sizeof(actmi_config)) + " (binding built against a different include/actmi.h)";
+        return ACTMI_E_INVALID;
+    }
     if (g.num_cams < 1 || g.max_batch < 1 || g.hidden_dim % g.nheads || (g.hidden_dim & 3) || (g.dim_feedforward & 3) ||
         (g.base_width & 3) || g.base_width > 64 || g.enc_layers < 1 || g.dec_layers < 1) {
         g_create_error = "unsupported configuration";

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ACTMI_VERSION 100
+#define ACTMI_VERSION 110
 
 #define ACTMI_OK 0
 #define ACTMI_E_INVALID (-1)   /* bad argument / unknown key / shape mismatch */
@@ -36,6 +36,10 @@ typedef struct actmi_ctx* actmi_handle;
 
 /* Model hyper-parameters: reference imitate_episodes.py:78-94 + detr/main.py:12-89 defaults. */
 typedef struct actmi_config {
+    /* ABI guard: set to sizeof(actmi_config) as the CALLER's binding declares it.  actmi_create rejects any other value
+     * with ACTMI_E_INVALID ("actmi_config.struct_size ..."), so a binding written against an older header (fewer trailing
+     * fields) fails loudly instead of having the library read past the end of its struct. */
+    uint32_t struct_size;
     int32_t num_cams;
     int32_t image_h, image_w;
     int32_t base_width;        /* resnet18 stem width (64) */

@@ -12,13 +12,13 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.actmi_version() == 100
+    assert lib.actmi_version() == 110
 
 
 def test_struct_sizes_match_header_layout():
     import ctypes as C
     # actmi_config: 16 int32 + 1 float
-    assert C.sizeof(L.ActmiConfig) == 20 * 4          # 16 ints, kl_weight, vq / vq_class / vq_dim
+    assert C.sizeof(L.ActmiConfig) == 21 * 4          # struct_size, 16 ints, kl_weight, vq / vq_class / vq_dim
     # descriptors: natural alignment, no packing pragmas on either side
     assert C.sizeof(L.GemmDesc) % 8 == 0 and C.sizeof(L.AttnDesc) % 8 == 0
 
