@@ -44,8 +44,12 @@ for p in (ROOT, os.path.join(ROOT, "act-plus-plus_amd")):
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3          # MI355X_MICROARCH.md, chip-level parameters
 PEAK_FP16_MATRIX_TFLOPS = 16 * 157.3     # dense F16/BF16 MFMA = 16x the f32 MFMA rate (same guide, matrix-core table)
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")      # falls back to the round-1 file when absent
-TRAFFIC_FALLBACK = os.path.join("profiles", "r01_j_traffic.json")
+# PMC traffic files, newest first: the first one that exists is read; its own stamp (commit + hash of the kernel sources it
+# was measured on) is printed next to the number and compared with the live tree (roofline.traffic_stale)
+TRAFFIC_FILES = [os.path.join("profiles", f) for f in ("r03_traffic.json", "r02_traffic.json", "r01_j_traffic.json")]
+
+# "dtype" of the JSON line: the type the path stores and accumulates in, with the way products are formed spelled out
+DTYPE = {"f16x3": "f32 (f16x3 split products: 3 fp16 MFMAs per fp32 product, fp32 accumulate)", "f32": "f32"}
 
 ARITH = {
     "f16x3": "fp32 in / fp32 out / fp32 accumulate; every GEMM, convolution (incl. the 7x7 stem) and attention product is "
@@ -85,20 +89,51 @@ def launch_ranks(args, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    import tempfile
+    import threading
     procs = []
+    # rank 0's stdout goes to a file (a pipe nobody drains could block it); the others' is dropped
+    out_f = tempfile.TemporaryFile(mode="w+")
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
+                                      stdout=out_f if r == 0 else subprocess.DEVNULL, text=True))
+    # supervise ALL ranks: the first non-zero exit (or the overall limit) ends the others -- a rank that died at start would
+    # otherwise leave rank 0 in init_process_group / a barrier until the RCCL timeout, holding the GPUs meanwhile
+    deadline = time.time() + float(os.environ.get("ACTMI_BENCH_LAUNCH_TIMEOUT_S", "3000"))
+    rcs = [None] * len(procs)
+    failed = False
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs) or time.time() > deadline:
+            failed = True
+            break
+        time.sleep(0.2)
+    if failed:
+        live = [p for p, rc in zip(procs, rcs) if rc is None]
+        for p in live:
+            p.terminate()                       # the exact children started above, never a pattern
+        t_kill = time.time() + 10.0
+        for p in live:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        rcs = [p.returncode for p in procs]
+    out_f.seek(0)
+    out0 = out_f.read()
+    out_f.close()
     line = None
     for ln in (out0 or "").splitlines():
         if ln.startswith("{"):
             line = ln
-    if any(rcs) or line is None:
-        print(f"bench.py: rank exit codes {rcs}; rank 0 printed {'no' if line is None else 'a'} JSON line", file=sys.stderr)
+    if failed or any(rcs) or line is None:
+        print(f"bench.py: rank exit codes {rcs}{' (siblings of the first failure were terminated)' if failed else ''}; "
+              f"rank 0 printed {'no' if line is None else 'a'} JSON line", file=sys.stderr)
         return 1
     print(line, flush=True)
     return 0
@@ -345,6 +380,10 @@ def bench_infer(args, cfg, B, ctx):
         elapsed = float(tt.item())
     assert torch.isfinite(rig.output()).all()
     rig.eng.check_flags()              # default-on range guard of the f16x3 arithmetic (reads the device flag word)
+    # which ranks took part: every rank's id through the eval path's own collective (all_gather_rows: RCCL when world > 1)
+    from actmi import dist_utils
+    ids = dist_utils.all_gather_rows(torch.full((1, 2), float(rank)), [1] * world)
+    ranks_seen = sorted(int(x) for x in ids[:, 0].tolist())
 
     # sustained leg: >= args.sustained_s of back-to-back steps (every rank runs it; max over ranks)
     sustained = None
@@ -370,12 +409,15 @@ def bench_infer(args, cfg, B, ctx):
     peak, peak_is = kernel_peak(dom["name"])
     # fabric traffic per launch of the dominant kernel: measured in separate rocprofv3 --pmc passes (FETCH_SIZE x2 for the
     # gfx950 under-count, + WRITE_SIZE) of this same command and COMMITTED under profiles/ -- read from there, not produced here
-    traffic, traffic_source = None, None
-    for f in (TRAFFIC_FILE, TRAFFIC_FALLBACK):
+    from actmi.buildinfo import kernel_source_sha16
+    live_sha = kernel_source_sha16()
+    traffic, traffic_source, traffic_commit, traffic_sha = None, None, None, None
+    for f in TRAFFIC_FILES:
         try:
             tj = json.load(open(os.path.join(ROOT, f)))
             key = dom["name"].split("[")[0]
             traffic = tj["kernels"][key]["traffic_bytes_per_launch"] if B == 8 else None
+            traffic_commit, traffic_sha = tj.get("commit"), tj.get("kernel_source_sha16")
             traffic_source = f + " (rocprofv3 --pmc passes of an earlier run of this command; not measured by this run)"
             break
         except Exception:
@@ -385,8 +427,9 @@ def bench_infer(args, cfg, B, ctx):
         "metric": "policy steps/sec (4x480x640 cams, chunk=100, bs=8)",
         "value": value, "unit": "policy steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": DTYPE["f32" if prec.startswith("f3") else "f16x3"], "data": "synthetic",
         "arithmetic": ARITH["f32" if prec.startswith("f3") else "f16x3"],
+        "kernel_source_sha16": live_sha,
         "config": {"workload": "ACT eval policy query: 4 cams 480x640 u8, chunk 100, hidden 512, ff 3200, "
                                "4 enc + 7 dec layers (layer 0 live), per-GPU batch %d, + temporal ensemble" % B,
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"replicas x{world}",
@@ -395,7 +438,11 @@ def bench_infer(args, cfg, B, ctx):
                      "measured": "per-launch HIP events on the launch stream, launches back to back on ONE stream (the profiled "
                                  "steps run the trunk as a single branch: events cannot bracket a launch that overlaps "
                                  "another branch's); extra.single_branch times the whole step that way",
-                     "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source, "peak_is": peak_is,
+                     "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source, "traffic_commit": traffic_commit,
+                     "traffic_kernel_source_sha16": traffic_sha,
+                     # True: the kernels changed since the PMC passes were taken (or the file carries no stamp)
+                     "traffic_stale": None if traffic is None else (traffic_sha != live_sha),
+                     "peak_is": peak_is,
                      "frac_of_native_fp32_mfma_peak": ach / PEAK_FP32_MATRIX_TFLOPS,
                      "avg_launch_us": dom["ms"] * 1e3 / dom["count"], "launches_per_step": dom["count"] / args.steps,
                      "flop_per_launch": dom["flops"] / dom["count"],
@@ -410,6 +457,7 @@ def bench_infer(args, cfg, B, ctx):
                      "note": "fresh u8 frames copied from pinned host memory every step (rank 0 only); not the headline"},
         "kernels": kernels,
         "step_latency_ms": lat,
+        "ranks_seen": ranks_seen,
     }
     if args.shapes:
         out["shapes"] = shape_table(prof, args.steps)
@@ -579,7 +627,7 @@ def bench_train(args, cfg, B, ctx):
         "metric": "ACT training samples/sec (fwd+bwd+AdamW, 4x480x640 cams, chunk=100)", "value": value,
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": DTYPE["f32" if os.environ.get("ACTMI_GEMM_PREC", "f16x3").startswith("f3") else "f16x3"], "data": "synthetic",
         "config": {"workload": f"ACT training step, per-GPU batch {B}, 4 cams 480x640, hidden 512, ff 3200, dropout 0",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single"},
         "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": kernel_peak(dom["name"])[0],
@@ -641,7 +689,7 @@ def bench_eval_shard(args, ctx):
     return {"metric": "policy steps/sec in episode-sharded eval rollouts (sim_insertion_scripted, 50 episodes/GPU)",
             "value": steps_total / elapsed, "unit": "policy steps/s", "n_gpus": world, "steps": ep_len, "warmup": 0,
             "ms_per_step": elapsed / ep_len * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": DTYPE["f32" if os.environ.get("ACTMI_GEMM_PREC", "f16x3").startswith("f3") else "f16x3"], "data": "synthetic",
             "config": {"workload": f"{task}: {n_total} episodes sharded {n_local}/GPU, {ep_len} timesteps, 3 cams 480x640 u8, "
                                    "temporal_agg, SyntheticEnv stand-in (dm_control absent), one all-gather of "
                                    "(episode_return, highest_reward)",

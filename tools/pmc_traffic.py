@@ -2,8 +2,12 @@
 """Per-launch HBM traffic of every kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), with the gfx950
 correction of MI355X_MICROARCH.md (FETCH_SIZE under-reports wide coalesced reads by exactly 2x; both counters are KiB).
 Kernel names are rewritten to the short names bench.py's in-library profiler uses, so that bench.py can look the
-dominant kernel up.  usage: pmc_traffic.py <fetch_counter_csv> <write_counter_csv> <out.json> [note]"""
-import csv, json, re, sys
+dominant kernel up.  The output records what it was measured on: the content hash of the kernel sources
+(actmi.buildinfo.kernel_source_sha16, computed where this script runs -- run it on the tree that produced the CSVs) and, when
+given, the commit.  usage: pmc_traffic.py <fetch_counter_csv> <write_counter_csv> <out.json> [note] [commit]"""
+import csv, json, os, re, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "act-plus-plus_amd"))
+from actmi.buildinfo import kernel_source_sha16
 from collections import defaultdict
 
 
@@ -30,7 +34,8 @@ def collect(path, counter):
 
 ft, fc = collect(sys.argv[1], "FETCH_SIZE")
 wt, wc = collect(sys.argv[2], "WRITE_SIZE")
-out = {"note": sys.argv[4] if len(sys.argv) > 4 else "", "kernels": {}}
+out = {"note": sys.argv[4] if len(sys.argv) > 4 else "", "commit": sys.argv[5] if len(sys.argv) > 5 else None,
+       "kernel_source_sha16": kernel_source_sha16(), "kernels": {}}
 for k in ft:
     f = ft[k] / max(fc[k], 1) * 1024 * 2
     w = wt.get(k, 0.0) / max(wc.get(k, 0), 1) * 1024
