@@ -102,6 +102,21 @@ def _alphas_cumprod(num_train_timesteps):
     return np.cumprod((1.0 - betas).astype(np.float32), dtype=np.float32)
 
 
+def _on_own_device(fn):
+    """Run a method with the net's device current: every ops.* wrapper launches on torch's CURRENT stream, which must be a
+    stream of the device the tensors live on (a process may hold nets on several GPUs)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        with torch.cuda.device(self.dev):
+            for t in list(a) + list(k.values()):
+                if torch.is_tensor(t) and t.is_cuda and t.device != self.dev:
+                    raise ValueError(f"tensor on {t.device} given to a DiffusionNet bound to {self.dev}")
+            return fn(self, *a, **k)
+    return wrapped
+
+
 class DiffusionNet:
     """Weights prepared once (OHWI convolution weights, unfolded Conv1d matrices, per-camera stacks) + the inference graph."""
 
@@ -116,6 +131,8 @@ class DiffusionNet:
         if num_train_timesteps % num_inference_timesteps:
             raise ValueError("num_inference_timesteps must divide the scheduler's num_train_timesteps")
         self.dev, self.prec = torch.device(device), gemm_prec
+        if self.dev.index is None:
+            self.dev = torch.device("cuda", torch.cuda.current_device())
         # f16x3 (fp32 products from exactly split fp16 pieces): weights of 1e-2 magnitude get a 2^8 pre-scale so that
         # their lo pieces stay normal fp16 numbers; gemm_prec="f32" runs the native fp32 matrix instruction
         self.bs = 256.0 if gemm_prec == "f16x3" else 0.0
@@ -185,7 +202,19 @@ class DiffusionNet:
         return missing, extra
 
     def state_dict(self):
-        return OrderedDict((k, v.clone()) for k, v in self.raw.items())
+        """The reference module's `nets.state_dict()`: the learned tensors plus the three buffers robomimic's SpatialSoftmax
+        registers per camera (temperature [1], pos_x / pos_y [1, 15*20] on the [-1, 1] grid of its fixed input_shape
+        [512, 15, 20], policy.py:46) -- the reference's strict load_state_dict wants them."""
+        out = OrderedDict()
+        px, py = np.meshgrid(np.linspace(-1.0, 1.0, 20), np.linspace(-1.0, 1.0, 15))
+        for k, v in self.raw.items():
+            out[k] = v.clone()
+            if k.startswith("policy.pools.") and k.endswith(".nets.bias"):
+                base = k[:-len("nets.bias")]
+                out[base + "temperature"] = torch.ones(1)
+                out[base + "pos_x"] = torch.from_numpy(px.reshape(1, -1)).float()
+                out[base + "pos_y"] = torch.from_numpy(py.reshape(1, -1)).float()
+        return out
 
     # ---- pieces -----------------------------------------------------------------------------------------------------
     def _gn_maps(self, x, gn, res=None, relu=True):
@@ -199,9 +228,13 @@ class DiffusionNet:
     def _conv(self, x, w, stride, pad):
         return ops.conv2d_nhwc(x, w, stride=stride, pad=pad, prec=self.prec, b_scale=self.bs)
 
+    @_on_own_device
     def obs_cond(self, qpos, image_u8):
         w = self.w
-        x = ops.u8_to_nhwc4(image_u8)                                     # [cam][B][H][W][4] in [0,1]: no ImageNet normalisation here
+        if image_u8.dtype == torch.uint8:
+            x = ops.u8_to_nhwc4(image_u8)                                 # [cam][B][H][W][4] in [0,1]: no ImageNet normalisation here
+        else:                                                             # f32 [B][cam][3][H][W] in [0,1] (the reference's contract)
+            x = torch.nn.functional.pad(image_u8.to(torch.float32).permute(1, 0, 3, 4, 2), (0, 1)).contiguous()
         x = self._conv(x, w["stem"], 2, 3)
         x = self._gn_maps(x, w["stem_gn"])
         ncam_, B_ = x.shape[0], x.shape[1]
@@ -246,6 +279,7 @@ class DiffusionNet:
         return ops.groupnorm(z, w[p + "blocks.1.block.1.weight"], w[p + "blocks.1.block.1.bias"], 8, act="mish", res=res,
                              res_after=True)
 
+    @_on_own_device
     def unet(self, sample, timestep, cond):
         """ConditionalUnet1D.forward on channel-last sequences: sample [B][T][A] -> noise prediction [B][T][A]."""
         w = self.w
@@ -278,6 +312,7 @@ class DiffusionNet:
         y = ops.groupnorm(y, w["final_conv.0.block.1.weight"], w["final_conv.0.block.1.bias"], 8, act="mish")
         return self._conv1d(y, "final_conv.1.weight", "final_conv.1.bias", 1)
 
+    @_on_own_device
     def forward_infer(self, qpos, image_u8, noise=None):
         """DiffusionPolicy.__call__(qpos, image) (policy.py:177-223): [B][Tp][A] action sequence.  `noise` replaces the
         torch.randn start (policy.py:203-205) for reproducible runs."""

@@ -118,6 +118,16 @@ class ACTEngine:
             out[prefix + k] = t
         return out
 
+    def parameters(self):
+        """nn.Module.parameters() of the reference model: one read-only float32 VIEW (no copy) per learnable state_dict entry,
+        in registration order (FrozenBatchNorm2d statistics are buffers, backbone.py:30-35, and are not listed)."""
+        for k, shape in self.spec.items():
+            if is_buffer(k):
+                continue
+            p, n = C.c_void_p(), C.c_int64()
+            L.check(self.lib.actmi_param_ptr(self.h, k.encode(), C.byref(p), C.byref(n)), self.h, f"param_ptr({k})")
+            yield _from_ptr(p.value, n.value, self.device).view(shape)
+
     def finalize(self):
         L.check(self.lib.actmi_finalize(self.h, self._sp()), self.h, "finalize")
         self._finalized = True
@@ -302,6 +312,7 @@ class ACTEngine:
         is a per-sample mean, policy.py:314-318,386-387)."""
         from .dist_utils import allreduce_buckets
         allreduce_buckets(self.grad_arena(), bucket_mb * (1 << 20) // 4, group)
+        self.sync_flags(group)
 
     def grad_phase_range(self, phase: int):
         off, cnt = C.c_int64(), C.c_int64()
@@ -330,6 +341,26 @@ class ACTEngine:
             allreduce_buckets(arena[lo:lo + n], bucket_mb * (1 << 20) // 4, group)       # under the rest of the backward
         allreduce_buckets(arena[lo + n:], bucket_mb * (1 << 20) // 4, group)             # after the backward has drained
         cur.wait_stream(side)
+        self.sync_flags(group)
+
+    def flags_tensor(self) -> torch.Tensor:
+        """int32 view (no copy) of the handle's device flag word."""
+        p = C.c_void_p()
+        L.check(self.lib.actmi_flags_ptr(self.h, C.byref(p)), self.h, "flags_ptr")
+        return _from_ptr(p.value, 1, self.device, typestr="<i4")
+
+    def sync_flags(self, group=None):
+        """OR the flag word over the data-parallel ranks (no host sync): the AdamW update is gated on it on the device, and
+        every rank must skip the same steps or the replicas diverge.  NCCL has no bitwise reduction: the three bits travel as
+        three integers under MAX."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        f = self.flags_tensor()
+        shifts = torch.arange(3, dtype=torch.int32, device=self.device)
+        bits = (f >> shifts) & 1
+        dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=group)
+        f.copy_((bits << shifts).sum(dtype=torch.int32).reshape(1) | f)
 
     def grad(self, key: str) -> torch.Tensor:
         """Copy of the gradient of one state_dict entry (shape of the parameter)."""
@@ -377,10 +408,10 @@ class ACTEngine:
         return t
 
 
-def _from_ptr(ptr: int, numel: int, device) -> torch.Tensor:
-    """View raw device memory as a float32 torch tensor (no ownership)."""
+def _from_ptr(ptr: int, numel: int, device, typestr: str = "<f4") -> torch.Tensor:
+    """View raw device memory as a float32 (or `typestr`) torch tensor (no ownership)."""
     class _Holder:
         pass
     h = _Holder()
-    h.__cuda_array_interface__ = {"shape": (numel,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+    h.__cuda_array_interface__ = {"shape": (numel,), "typestr": typestr, "data": (ptr, False), "version": 2}
     return torch.as_tensor(h, device=device)

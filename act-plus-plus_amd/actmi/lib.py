@@ -106,6 +106,7 @@ def load():
         "actmi_param_info": ([vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)], i32),
         "actmi_set_param": ([vp, C.c_char_p, vp, C.POINTER(i64), i32, i32], i32),
         "actmi_get_param": ([vp, C.c_char_p, vp, i64, i32], i32),
+        "actmi_param_ptr": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i64)], i32),
         "actmi_finalize": ([vp, vp], i32),
         "actmi_forward_infer_vq": ([vp, vp, vp, i32, i32, vp, vp, vp], i32),
         "actmi_forward_infer": ([vp, vp, vp, i32, i32, vp, vp], i32),
@@ -145,6 +146,7 @@ def load():
         "actmi_debug_stop_after": ([vp, C.c_char_p], i32),
         "actmi_set_gemm_prec": ([vp, i32], i32),
         "actmi_get_flags": ([vp, C.POINTER(C.c_uint32), i32, vp], i32),
+        "actmi_flags_ptr": ([vp, C.POINTER(vp)], i32),
         "actmi_profile_enable": ([i32], i32),
         "actmi_profile_reset": ([], i32),
         "actmi_profile_report": ([C.c_char_p, i32], i32),

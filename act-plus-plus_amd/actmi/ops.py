@@ -354,9 +354,12 @@ def groupnorm(x, weight, bias, groups, eps=1e-5, act=None, res=None, res_after=F
     assert out.is_contiguous() and out.shape == x.shape
     fs, fb = (film[0].contiguous(), film[1].contiguous()) if film is not None else (None, None)
     rm = 0 if res is None else (2 if res_after else 1)
-    ws = _GN_WS.get(x.device)                 # chunk statistics of the large-map path (3 floats per sample, group, chunk)
+    # chunk statistics of the large-map path (3 floats per sample, group, chunk): one workspace per (device, stream) -- two
+    # streams normalising concurrently must not share it
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _GN_WS.get(key)
     if ws is None:
-        ws = _GN_WS[x.device] = torch.empty(1 << 20, dtype=torch.float32, device=x.device)
+        ws = _GN_WS[key] = torch.empty(1 << 20, dtype=torch.float32, device=x.device)
     L.check(lib.actmi_op_groupnorm(_p(x), _p(res.contiguous() if res is not None else None), _p(fs), _p(fb), _p(weight), _p(bias),
                                    _p(out), n, P, Cc, int(groups), float(eps), ACT[act], rm, _p(ws), ws.numel(),
                                    L.current_stream_ptr()), None, "op_groupnorm")

@@ -451,10 +451,15 @@ __global__ void reparam_kl_bwd_kernel(const float* __restrict__ latent_info, con
 // ---------------------------------------------------------------------------------------------- AdamW
 // torch.optim.AdamW (single-tensor formulation) over the whole parameter arena.  group[chunk] per 64-float slot:
 // 0 = frozen/buffer/no-grad (skipped entirely, like params whose .grad is None), 1 = lr, 2 = lr_backbone.
+// flags / skip_mask: the handle's device flag word; when any bit of skip_mask is up (a non-finite loss of this step's forward,
+// a weight beyond its split scale) the whole update is skipped ON THE DEVICE -- no host sync, and NaN gradients never reach the
+// fp32 master weights or the Adam moments (the host reads the word at its next natural synchronisation and raises)
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     const uint8_t* __restrict__ group, int64_t n, float lr, float lr_bb,
-                                                    float wd, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+                                                    float wd, float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                    const uint32_t* __restrict__ flags, uint32_t skip_mask) {
+    if (flags && (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & skip_mask)) return;      // grid-uniform
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint8_t gr = group[i >> 6];
         if (!gr) continue;
@@ -876,12 +881,12 @@ int launch_reparam_kl_bwd(const float* latent_info, const float* eps, const floa
 }
 
 int launch_adamw(float* p, const float* g, float* m, float* v, const uint8_t* group, int64_t n, float lr, float lr_bb,
-                 float wd, float b1, float b2, float eps, int64_t step, hipStream_t st) {
+                 float wd, float b1, float b2, float eps, int64_t step, hipStream_t st, const uint32_t* flags, uint32_t skip_mask) {
     const float bc1 = 1.f - powf(b1, (float)step);
     const float bc2 = 1.f - powf(b2, (float)step);
     prof_begin("adamw_kernel", 0.0, 28.0 * (double)n, st);
     hipLaunchKernelGGL(adamw_kernel, dim3(256 * 8), dim3(256), 0, st, p, g, m, v, group, n, lr, lr_bb, wd, b1, b2, eps, bc1,
-                       sqrtf(bc2));
+                       sqrtf(bc2), flags, skip_mask);
     prof_end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

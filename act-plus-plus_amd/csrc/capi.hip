@@ -87,6 +87,17 @@ int actmi_get_param(actmi_handle h, const char* key, void* dst, int64_t nbytes, 
     return 0;
 }
 
+int actmi_param_ptr(actmi_handle h, const char* key, void** dev_ptr, int64_t* numel) {
+    if (!h || !key) return ACTMI_E_INVALID;
+    ENTER(h);
+    auto it = h->index.find(key);
+    if (it == h->index.end()) return bad(h, std::string("unknown state_dict key: ") + key);
+    const Param& p = h->params[it->second];
+    if (dev_ptr) *dev_ptr = h->pbase + p.off;
+    if (numel) *numel = p.numel;
+    return 0;
+}
+
 int actmi_finalize(actmi_handle h, void* stream) {
     if (!h) return ACTMI_E_INVALID;
     ENTER(h);
@@ -346,6 +357,12 @@ int actmi_get_flags(actmi_handle h, uint32_t* host_flags, int clear, void* strea
     if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
     if (e == hipSuccess && clear && *host_flags) e = hipMemsetAsync(h->flags, 0, sizeof(uint32_t), S(stream));
     if (e != hipSuccess) return bad(h, std::string("get_flags: ") + hipGetErrorString(e), ACTMI_E_LAUNCH);
+    return 0;
+}
+
+int actmi_flags_ptr(actmi_handle h, void** dev_ptr) {
+    if (!h || !dev_ptr) return ACTMI_E_INVALID;
+    *dev_ptr = h->flags;
     return 0;
 }
 

@@ -177,7 +177,8 @@ int launch_vq_code(const float* logits, const float* code_in, uint64_t seed, flo
                    hipStream_t st, float temperature = 1.f);
 int launch_vq_bwd(const float* probs, const float* g, float* dlogits, int B, int VC, int VD, hipStream_t st);
 int launch_adamw(float* p, const float* g, float* m, float* v, const uint8_t* group, int64_t n, float lr, float lr_bb,
-                 float wd, float b1, float b2, float eps, int64_t step, hipStream_t st);
+                 float wd, float b1, float b2, float eps, int64_t step, hipStream_t st, const uint32_t* flags = nullptr,
+                 uint32_t skip_mask = 0);
 int launch_repack_dgrad_w(const float* wf, float* wd, int G, int O, int I, int KK, hipStream_t st, int flip = 0);
 int launch_unpack_wgrad(const float* gp, float* g_oihw, int O, int I, int KH, int KW, int kpad, int ipack, hipStream_t st, int G = 1,
                         int64_t g_gp = 0, int64_t g_out = 0);

@@ -680,6 +680,43 @@ int engine_finalize(actmi_ctx* ctx, hipStream_t st) {
 // forward pieces
 // ------------------------------------------------------------------------------------------------
 
+// nb concurrent branches of one forward: branch 0 on the caller's stream, branch i > 0 on ctx->pipe_streams[i - 1], forked from
+// and joined back into the caller's stream with events (parallel branches of the graph under capture).  Whatever fails -- a
+// launch inside a branch or the event plumbing itself -- every stream that WAS forked is still joined before the first error
+// is returned (an early return left forked streams unjoined, which under hipGraph capture voids the capture with
+// a secondary StreamCaptureUnjoined error that hid the real cause, and in eager mode let branch work race the next call).
+template <class Body>
+static int run_branches(actmi_ctx* ctx, int nb, hipStream_t st, Body body) {
+    ctx->policy_mult = nb;
+    int rc = 0;
+    hipError_t he = hipEventRecord(ctx->ev_pfork, st);
+    const char* he_where = "hipEventRecord(fork)";
+    bool forked[4] = {false, false, false, false};
+    for (int i = nb - 1; i >= 0; --i) {
+        if (rc != 0 || he != hipSuccess) break;
+        hipStream_t bs = i ? ctx->pipe_streams[i - 1] : st;
+        if (i) {
+            he = hipStreamWaitEvent(bs, ctx->ev_pfork, 0);
+            if (he != hipSuccess) { he_where = "hipStreamWaitEvent(fork)"; break; }
+            forked[i] = true;
+        }
+        rc = body(i, bs);               // leaves its message in ctx->err (first error wins: CHK / HIPCHK)
+    }
+    for (int i = 1; i < nb; ++i) {      // join every forked branch, error or not
+        if (!forked[i]) continue;
+        hipError_t e = hipEventRecord(ctx->ev_pjoins[i - 1], ctx->pipe_streams[i - 1]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->ev_pjoins[i - 1], 0);
+        if (e != hipSuccess && he == hipSuccess) { he = e; he_where = "branch join"; }
+    }
+    ctx->policy_mult = 1;
+    if (rc != 0) return rc;
+    if (he != hipSuccess) {
+        if (ctx->err.empty()) ctx->err = std::string(he_where) + ": " + hipGetErrorString(he);
+        return ACTMI_E_LAUNCH;
+    }
+    return 0;
+}
+
 // multi-camera ResNet18 trunk + input_proj -> token rows 2.. of X   (backbone.py:66-71, detr_vae.py:180-185)
 int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream_t st) {
     const actmi_config& g = ctx->cfg;
@@ -786,10 +823,15 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
                         // captured graph these are two parallel branches) and fills CUs that launch leaves idle
                         HIPCHK(hipEventRecord(ctx->ev_fork, ls));
                         HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
-                        CHK(run_conv_on(ds, cur, s2, nullptr, 0, ctx->side_stream, c0, nc, half));
-                        HIPCHK(hipEventRecord(ctx->ev_join, ctx->side_stream));
-                        CHK(run_conv(k1, cur, s1, nullptr, 1));
-                        HIPCHK(hipStreamWaitEvent(ls, ctx->ev_join, 0));
+                        // from here the side stream is forked: join it whatever happens, then report the first error
+                        const int r1 = run_conv_on(ds, cur, s2, nullptr, 0, ctx->side_stream, c0, nc, half);
+                        const hipError_t e1 = hipEventRecord(ctx->ev_join, ctx->side_stream);
+                        const int r2 = r1 == 0 ? run_conv(k1, cur, s1, nullptr, 1) : 0;
+                        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(ls, ctx->ev_join, 0) : e1;
+                        CHK(r1);
+                        CHK(r2);
+                        HIPCHK(e1);
+                        HIPCHK(e2);
                     } else {
                         CHK(run_conv(k1, cur, s1, nullptr, 1));
                         CHK(run_conv(ds, cur, s2, nullptr, 0));
@@ -823,19 +865,12 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
         // 512 slots) the other half's current launch fills the CUs, and no launch boundary drains the whole chip
         // branch i takes the cameras [i C / nb, (i+1) C / nb); branch 0 runs on the caller's stream
         const int nb = C < ctx->nbranch ? C : ctx->nbranch;
-        ctx->policy_mult = nb;
-        HIPCHK(hipEventRecord(ctx->ev_pfork, st));
-        int rc = 0;
-        for (int i = nb - 1; i >= 0 && rc == 0; --i) {
+        const int rc = run_branches(ctx, nb, st, [&](int i, hipStream_t bs) -> int {
             const int c0 = i * C / nb, c1 = (i + 1) * C / nb;
-            hipStream_t bs = i ? ctx->pipe_streams[i - 1] : st;
-            if (i) HIPCHK(hipStreamWaitEvent(bs, ctx->ev_pfork, 0));
-            if (pipe_early) rc = run_stem(c0, c1 - c0, bs);
-            if (rc == 0) rc = run_layers(c0, c1 - c0, bs, i);
-            if (i) HIPCHK(hipEventRecord(ctx->ev_pjoins[i - 1], bs));
-        }
-        for (int i = 1; i < nb; ++i) HIPCHK(hipStreamWaitEvent(st, ctx->ev_pjoins[i - 1], 0));     // join (after branch 0 is queued)
-        ctx->policy_mult = 1;
+            int r = pipe_early ? run_stem(c0, c1 - c0, bs) : 0;
+            if (r == 0) r = run_layers(c0, c1 - c0, bs, i);
+            return r;
+        });
         if (rc != 0) return rc;
     } else {
         const int rc = run_layers(0, C, st, -1);
@@ -988,18 +1023,10 @@ int engine_forward_infer(actmi_ctx* ctx, const float* qpos, const void* image, i
     ctx->dbg["memory"] = {ctx->X, (int64_t)B * N * D};
     if (tpipe) {
         const int nb = B < ctx->nbranch ? B : ctx->nbranch;
-        ctx->policy_mult = nb;
-        HIPCHK(hipEventRecord(ctx->ev_pfork, st));
-        int rc = 0;
-        for (int i = nb - 1; i >= 0 && rc == 0; --i) {
+        const int rc = run_branches(ctx, nb, st, [&](int i, hipStream_t bs) -> int {
             const int b0 = i * B / nb, b1 = (i + 1) * B / nb;
-            hipStream_t bs = i ? ctx->pipe_streams[i - 1] : st;
-            if (i) HIPCHK(hipStreamWaitEvent(bs, ctx->ev_pfork, 0));
-            rc = run_transformer(b0, b1 - b0, bs, i);
-            if (i) HIPCHK(hipEventRecord(ctx->ev_pjoins[i - 1], bs));
-        }
-        for (int i = 1; i < nb; ++i) HIPCHK(hipStreamWaitEvent(st, ctx->ev_pjoins[i - 1], 0));     // join (after branch 0 is queued)
-        ctx->policy_mult = 1;
+            return run_transformer(b0, b1 - b0, bs, i);
+        });
         if (rc != 0) return rc;
     } else {
         CHK(run_transformer(0, B, st, -1));

@@ -1082,6 +1082,9 @@ int train_adamw_step(actmi_ctx* ctx, float lr, float lr_backbone, float wd, floa
                      hipStream_t st) {
     if (!ctx->train) { ctx->err = "handle was created without enable_training"; return ACTMI_E_STATE; }
     TrainState& T = *ctx->train;
-    CHK(launch_adamw(ctx->pbase, T.gbase, T.mbase, T.vbase, T.group, ctx->ptotal, lr, lr_backbone, wd, b1, b2, eps, step, st));
+    // gated on the device by the handle's flag word: after a non-finite loss or a weight beyond its split scale the
+    // update is skipped until the host has read and cleared the word (actmi_get_flags) -- weights and moments stay intact
+    CHK(launch_adamw(ctx->pbase, T.gbase, T.mbase, T.vbase, T.group, ctx->ptotal, lr, lr_backbone, wd, b1, b2, eps, step, st,
+                     ctx->flags, ACTMI_FLAG_LOSS | ACTMI_FLAG_WEIGHT));
     return engine_prepare_weights(ctx, st, true); // conv repack, decoder constants, learned pos rows follow the new weights
 }

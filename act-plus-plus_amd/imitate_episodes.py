@@ -49,12 +49,34 @@ def make_optimizer(policy_class, policy):
     raise NotImplementedError
 
 
+def center_crop_resize(image, ratio=0.95):
+    """The Diffusion policy's eval-time image transform (reference imitate_episodes.py:214-224): the centre `ratio` crop of
+    f32 [..., H, W] images, resized back to (H, W).  torchvision's ``transforms.Resize(size, antialias=True)`` on a tensor is
+    ``F.interpolate(mode='bilinear', align_corners=False, antialias=True)``, which is what runs here (torchvision itself is
+    not importable offline)."""
+    H, W = image.shape[-2:]
+    crop = image[..., int(H * (1 - ratio) / 2): int(H * (1 + ratio) / 2), int(W * (1 - ratio) / 2): int(W * (1 + ratio) / 2)]
+    lead = crop.shape[:-3]
+    out = torch.nn.functional.interpolate(crop.reshape(-1, *crop.shape[-3:]), size=(H, W), mode="bilinear", align_corners=False,
+                                          antialias=True)
+    return out.reshape(*lead, *out.shape[-3:])
+
+
 def get_image(ts, camera_names, rand_crop_resize=False):
     """reference imitate_episodes.py:206-225: one timestep -> f32 [1,C,3,H,W] in [0,1] on the GPU."""
-    if rand_crop_resize:
-        raise NotImplementedError("rand_crop_resize is only used by the Diffusion policy")
     imgs = np.stack([np.moveaxis(ts.observation["images"][c], -1, 0) for c in camera_names], axis=0)
-    return torch.from_numpy(imgs / 255.0).float().cuda().unsqueeze(0)
+    curr_image = torch.from_numpy(imgs / 255.0).float().cuda().unsqueeze(0)
+    if rand_crop_resize:
+        curr_image = center_crop_resize(curr_image)
+    return curr_image
+
+
+def make_post_process(policy_class, stats):
+    """reference imitate_episodes.py:290-293: Diffusion policies emit actions in [-1, 1] of the dataset's min / max range,
+    the others z-scored actions."""
+    if policy_class == "Diffusion":
+        return lambda a: ((a + 1) / 2) * (stats["action_max"] - stats["action_min"]) + stats["action_min"]
+    return lambda a: a * stats["action_std"] + stats["action_mean"]
 
 
 def get_image_batch_u8(ts_list, camera_names, pinned=None):
@@ -75,7 +97,8 @@ def get_image_batch_u8(ts_list, camera_names, pinned=None):
 
 def _default_stats(state_dim, action_dim=16):
     return {"qpos_mean": np.zeros(state_dim), "qpos_std": np.ones(state_dim),
-            "action_mean": np.zeros(action_dim), "action_std": np.ones(action_dim)}
+            "action_mean": np.zeros(action_dim), "action_std": np.ones(action_dim),
+            "action_min": -np.ones(action_dim), "action_max": np.ones(action_dim)}
 
 
 def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, ensemble_factory=None,
@@ -120,7 +143,8 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
         else:
             stats = _default_stats(state_dim)
     pre_process = lambda s_qpos: (s_qpos - stats["qpos_mean"]) / stats["qpos_std"]          # noqa: E731
-    post_process = lambda a: a * stats["action_std"] + stats["action_mean"]                  # noqa: E731
+    post_process = make_post_process(policy_class, stats)
+    is_diffusion = policy_class == "Diffusion"
 
     use_vq = bool(policy_config.get("vq", False))
     if use_vq and vq_sampler is None:
@@ -180,7 +204,9 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
         envs = [env_factory(poses[i], i) for i in ids]
         env_max_reward = envs[0].task.max_reward
         ts_list = list(pool.map(lambda e: e.reset(), envs))
-        ens = ensemble_factory(E) if temporal_agg else None
+        # the reference's Diffusion branch never ensembles (imitate_episodes.py:417-423): with temporal_agg it re-queries every
+        # step (query_frequency = 1) and takes the first action of the new chunk
+        ens = ensemble_factory(E) if (temporal_agg and not is_diffusion) else None
         rewards = [[] for _ in range(E)]
         pinned, all_actions = None, None
         time0 = time.time()
@@ -191,6 +217,10 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
             if t % query_frequency == 0:
                 pinned = get_image_batch_u8(ts_list, camera_names, pinned)
                 curr_image = pinned.to(dev, non_blocking=True)
+                if is_diffusion:
+                    # get_image(..., rand_crop_resize=True) of the reference (:214-224, :374): f32 in [0, 1], centre 0.95 crop,
+                    # resized back -- on the device, for all E episodes at once
+                    curr_image = center_crop_resize(curr_image.permute(0, 1, 4, 2, 3).float().div(255.0))
                 if t == 0:
                     for _ in range(warmup_queries):
                         policy(qpos, curr_image, vq_sample=vq_sampler(qpos.shape[0])) if use_vq else policy(qpos, curr_image)
@@ -198,7 +228,7 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
                 all_actions = (policy(qpos, curr_image, vq_sample=vq_sampler(qpos.shape[0])) if use_vq
                                else policy(qpos, curr_image))                # [E,Q,A]
                 n_queries += E
-            if temporal_agg:
+            if ens is not None:
                 raw_action = ens.step(all_actions)                           # [E,A] float64, like the reference
             else:
                 raw_action = all_actions[:, t % query_frequency]
@@ -264,6 +294,7 @@ def train_bc(train_dataloader, val_dataloader, config, log=None):
     seed = config["seed"]
     policy_class = config["policy_class"]
     policy_config = config["policy_config"]
+    eval_every = config.get("eval_every") or 0
     validate_every = config["validate_every"]
     save_every = config["save_every"]
     # data parallel (one process per GPU under torch.distributed.run): every rank builds the same initial policy on its own
@@ -273,6 +304,15 @@ def train_bc(train_dataloader, val_dataloader, config, log=None):
     set_seed(seed + rank)
     dev = f"cuda:{local_rank}" if world > 1 else None
     policy = make_policy(policy_class, dict(policy_config, seed=policy_config.get("seed", seed) * world + rank), device=dev)
+    if config.get("load_pretrain"):
+        # reference :548-550 reads a path in its author's home directory; here: config["pretrain_ckpt_path"], else the
+        # environment's ACTMI_PRETRAIN_CKPT, else that same path -- and a missing file is an error, not a silent skip
+        pre = (config.get("pretrain_ckpt_path") or os.environ.get("ACTMI_PRETRAIN_CKPT") or
+               os.path.join("/home/zfu/interbotix_ws/src/act/ckpts/pretrain_all", "policy_step_50000_seed_0.ckpt"))
+        if not os.path.isfile(pre):
+            raise FileNotFoundError(f"--load_pretrain: no checkpoint at {pre} (set --pretrain_ckpt_path or ACTMI_PRETRAIN_CKPT)")
+        loading_status = policy.deserialize(torch.load(pre, weights_only=True))
+        print(f"loaded! {loading_status}")
     if config.get("resume_ckpt_path"):
         loading_status = policy.deserialize(torch.load(config["resume_ckpt_path"], weights_only=True))
         print(f'Resume policy from: {config["resume_ckpt_path"]}, Status: {loading_status}')
@@ -299,6 +339,17 @@ def train_bc(train_dataloader, val_dataloader, config, log=None):
             if log:
                 log({f"val_{k}": float(v) for k, v in validation_summary.items()}, step)
             print(f"Val loss:   {epoch_val_loss:.5f}")
+        if eval_every and step > 0 and step % eval_every == 0:
+            # reference :590-596: first save, then evaluate that checkpoint with 10 rollouts (eval_bc builds its own
+            # inference-only handle from the file; under data-parallel training the rollouts shard over the ranks)
+            ckpt_name = f"policy_step_{step}_seed_{seed}.ckpt"
+            if rank == 0:
+                torch.save(policy.serialize(), os.path.join(ckpt_dir, ckpt_name))
+            dist_utils.barrier()
+            success, _ = eval_bc(config, ckpt_name, save_episode=True, num_rollouts=config.get("eval_rollouts", 10),
+                                 verbose=(rank == 0))
+            if log:
+                log({"success": success}, step)
         policy.train()
         optimizer.zero_grad()
         data = next(train_dataloader)
@@ -336,19 +387,28 @@ def build_config(args):
     task_name = args["task_name"]
     task_config = SIM_TASK_CONFIGS[task_name]
     camera_names = task_config["camera_names"]
-    policy_config = {"lr": args["lr"], "num_queries": args["chunk_size"], "kl_weight": args["kl_weight"],
-                     "hidden_dim": args["hidden_dim"], "dim_feedforward": args["dim_feedforward"], "lr_backbone": 1e-5,
-                     "backbone": "resnet18", "enc_layers": 4, "dec_layers": 7, "nheads": 8,
-                     "camera_names": camera_names, "vq": args.get("use_vq", False), "vq_class": args.get("vq_class"),
-                     "vq_dim": args.get("vq_dim"), "action_dim": 16, "no_encoder": args.get("no_encoder", False),
-                     "state_dim": 14, "max_batch": args.get("max_batch") or args["batch_size"]}
+    policy_class = args["policy_class"]
+    if policy_class == "ACT":                        # reference :74-94
+        policy_config = {"lr": args["lr"], "num_queries": args["chunk_size"], "kl_weight": args["kl_weight"],
+                         "hidden_dim": args["hidden_dim"], "dim_feedforward": args["dim_feedforward"], "lr_backbone": 1e-5,
+                         "backbone": "resnet18", "enc_layers": 4, "dec_layers": 7, "nheads": 8,
+                         "camera_names": camera_names, "vq": args.get("use_vq", False), "vq_class": args.get("vq_class"),
+                         "vq_dim": args.get("vq_dim"), "action_dim": 16, "no_encoder": args.get("no_encoder", False),
+                         "state_dim": 14, "max_batch": args.get("max_batch") or args["batch_size"]}
+    elif policy_class == "Diffusion":                # reference :95-106
+        policy_config = {"lr": args["lr"], "camera_names": camera_names, "action_dim": 16, "observation_horizon": 1,
+                         "action_horizon": 8, "prediction_horizon": args["chunk_size"], "num_queries": args["chunk_size"],
+                         "num_inference_timesteps": 10, "ema_power": 0.75, "vq": False}
+    else:
+        raise NotImplementedError(f"policy_class {policy_class} is outside the accelerated path (SURVEY §2)")
     return {"num_steps": args["num_steps"], "eval_every": args["eval_every"], "validate_every": args["validate_every"],
             "save_every": args["save_every"], "ckpt_dir": args["ckpt_dir"], "resume_ckpt_path": args.get("resume_ckpt_path"),
             "episode_len": task_config["episode_len"], "state_dim": 14, "lr": args["lr"],
             "policy_class": args["policy_class"], "onscreen_render": args.get("onscreen_render", False),
             "policy_config": policy_config, "task_name": task_name, "seed": args["seed"],
             "temporal_agg": args["temporal_agg"], "camera_names": camera_names, "real_robot": False,
-            "load_pretrain": False, "synthetic_env": bool(args.get("synthetic_env", False))}
+            "load_pretrain": bool(args.get("load_pretrain", False)), "pretrain_ckpt_path": args.get("pretrain_ckpt_path"),
+            "synthetic_env": bool(args.get("synthetic_env", False))}
 
 
 def main(args):
@@ -409,6 +469,8 @@ if __name__ == "__main__":
     parser.add_argument("--num_steps", action="store", type=int, required=True)
     parser.add_argument("--lr", action="store", type=float, required=True)
     parser.add_argument("--load_pretrain", action="store_true", default=False)
+    parser.add_argument("--pretrain_ckpt_path", action="store", type=str, default=None,
+                        help="checkpoint --load_pretrain reads (the reference hard-codes a path in its author's home directory)")
     parser.add_argument("--eval_every", action="store", type=int, default=500)
     parser.add_argument("--validate_every", action="store", type=int, default=500)
     parser.add_argument("--save_every", action="store", type=int, default=500)

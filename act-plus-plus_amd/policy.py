@@ -116,7 +116,8 @@ class ACTPolicy:
         return self
 
     def parameters(self):
-        return iter(())
+        """nn.Module.parameters() (the reference counts them at detr/main.py:99-100): read-only views of the fp32 master copy"""
+        return self.model.parameters()
 
     def configure_optimizers(self):
         return self.optimizer
@@ -176,9 +177,8 @@ class DiffusionPolicy:
     def __call__(self, qpos, image, actions=None, is_pad=None, depth_img=None, noise=None):
         if actions is not None:
             raise NotImplementedError("DiffusionPolicy training is outside the accelerated path (SURVEY 8 f2): inference only")
-        if image.dtype != torch.uint8:
-            # the reference contract: f32 [B, cams, 3, H, W] in [0, 1] (imitate_episodes.py:206-225) -> the u8 NHWC fast path
-            image = (image.clamp(0, 1) * 255.0).round().to(torch.uint8).permute(0, 1, 3, 4, 2).contiguous()
+        # u8 NHWC [B, cams, H, W, 3] (fast path) or the reference contract f32 [B, cams, 3, H, W] in [0, 1]
+        # (imitate_episodes.py:206-225; the eval-time crop + resize makes it non-integer, so it is NOT re-quantised)
         return self.model.forward_infer(qpos, image, noise=noise)
 
     def cuda(self):

@@ -243,6 +243,9 @@ int actmi_num_params(actmi_handle h);
 int actmi_param_info(actmi_handle h, int index, const char** key, int64_t* shape4, int* ndim, int* is_buffer);
 int actmi_set_param(actmi_handle h, const char* key, const void* src, const int64_t* shape, int ndim, int is_device);
 int actmi_get_param(actmi_handle h, const char* key, void* dst, int64_t nbytes, int is_device);
+/* device address of a parameter's fp32 master copy inside the handle's arena (nn.Module.parameters() views, policy.py:243;
+ * READ-ONLY for the caller: derived weights are rebuilt only by actmi_set_param + actmi_finalize / actmi_adamw_step) */
+int actmi_param_ptr(actmi_handle h, const char* key, void** dev_ptr, int64_t* numel);
 /* fold FrozenBN, repack conv weights, build position tables and the constant decoder query path.
  * Must be called after the last set_param and before the first forward. */
 int actmi_finalize(actmi_handle h, void* stream);
@@ -263,7 +266,10 @@ int actmi_forward_train(actmi_handle h, const float* qpos, const void* image, in
                         float* losses /*[3] l1, kl, loss*/, float* a_hat, float* mu, float* logvar, void* stream);
 /* loss.backward() (imitate_episodes.py:606) */
 int actmi_backward(actmi_handle h, float loss_scale, void* stream);
-/* optimizer.zero_grad() / optimizer.step() with the two AdamW groups of detr/main.py:102-110 */
+/* optimizer.zero_grad() / optimizer.step() with the two AdamW groups of detr/main.py:102-110.
+ * actmi_adamw_step is gated ON THE DEVICE by the handle's flag word: while ACTMI_FLAG_LOSS or ACTMI_FLAG_WEIGHT is up (a
+ * non-finite training loss, a weight beyond its split scale) the update is skipped -- parameters and Adam moments stay
+ * untouched until the host has read and cleared the word with actmi_get_flags (and re-finalized for _WEIGHT). */
 int actmi_zero_grad(actmi_handle h, void* stream);
 int actmi_adamw_step(actmi_handle h, float lr, float lr_backbone, float weight_decay, float beta1, float beta2,
                      float eps, int64_t step, void* stream);
@@ -386,6 +392,9 @@ int actmi_set_gemm_prec(actmi_handle h, int prec);
 #define ACTMI_FLAG_WEIGHT 2u
 #define ACTMI_FLAG_LOSS 4u
 int actmi_get_flags(actmi_handle h, uint32_t* host_flags, int clear, void* stream);
+/* device address of the flag word (one uint32): data-parallel callers reduce it over the ranks before actmi_adamw_step so
+ * that every rank skips the same updates (actmi/engine.py:backward_allreduce) */
+int actmi_flags_ptr(actmi_handle h, void** dev_ptr);
 
 /* ---- per-launch HIP-event profiler (bench.py roofline leg) --------------------------------------- */
 /* When enabled, every kernel launch of the library is bracketed by two events on its stream.  The report is a

@@ -21,11 +21,6 @@ def _engine(cfg, sd_np, max_batch, prec=None):
     return eng
 
 
-def _to_nchw(t, G, B):
-    """camera-major NHWC [G*B,H,W,C] flat -> [B,C,H,W] of camera 0 for comparison with the oracle's NCHW maps."""
-    return t
-
-
 @pytest.mark.parametrize("prec", ["f16x3", "f32"])
 @pytest.mark.parametrize("name", ["tiny", "tiny_c3", "full3", "full4"])
 def test_forward_matches_reference_golden(name, prec):

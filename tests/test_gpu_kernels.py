@@ -331,13 +331,44 @@ def test_ensemble_matches_reference_transcription():
         pop = ens.populated.cpu().numpy()
         for e in range(E):
             raw, popref = refs[e].step(t, torch.from_numpy(chunks[t, e:e + 1]))
-            if int(popref.sum()) == 0:
-                continue            # reference would produce an empty sum (zeros); never happens with real chunks
             assert out.dtype == torch.float64
             assert np.allclose(out[e].numpy(), raw.numpy()[0], rtol=0, atol=1e-13)
             ref_rows = popref.numpy()[max(0, t - Q + 1):t + 1]
             mine = pop[e][Q - len(ref_rows):]
             assert np.array_equal(mine.astype(bool), ref_rows)       # populated mask: bit exact
+
+
+def test_ensemble_with_no_populated_row_is_the_reference_empty_sum():
+    """Edge case of imitate_episodes.py:405-410: when NO row for the current step passes `all(actions != 0)` the reference
+    indexes an empty set, its weights are an empty array (0/0 never evaluated) and the sum over zero rows is zeros[1, A].
+    The kernel (misc.hip: w = 0 for every row) must give exactly that, with an all-false populated mask, and carry on
+    correctly on the following steps."""
+    from oracle.act_ref import TemporalEnsembleRef
+    E, T, Q, A = 3, 6, 4, 16
+    rng = np.random.default_rng(5)
+    chunks = rng.standard_normal((T, E, Q, A)).astype(np.float32)
+    chunks[0, 0, 0, 3] = 0.0             # episode 0, t = 0: the only row for step 0 has a zero -> nothing populated
+    chunks[0, 1, :, :] = 0.0             # episode 1: an all-zero first chunk -> nothing populated at t = 0
+    chunks[1, 1, 0, 0] = 0.0             # ... and at t = 1 both candidate rows fail (old row all zero, new row has a zero)
+    chunks[2, 2, 0, 5] = 0.0             # episode 2, t = 2: the newest row fails, the two older ones count
+    refs = [TemporalEnsembleRef(T, Q, A) for _ in range(E)]
+    ens = ops.TemporalEnsemble(E, Q, A, 0.01, dev())
+    n_empty = 0
+    for t in range(T):
+        out = ens.step(torch.from_numpy(chunks[t]).to(dev())).cpu()
+        pop = ens.populated.cpu().numpy()
+        for e in range(E):
+            raw, popref = refs[e].step(t, torch.from_numpy(chunks[t, e:e + 1]))
+            ref_rows = popref.numpy()[max(0, t - Q + 1):t + 1]
+            assert np.array_equal(pop[e][Q - len(ref_rows):].astype(bool), ref_rows)
+            assert not pop[e][:Q - len(ref_rows)].any()                  # rows before the episode began never count
+            if int(popref.sum()) == 0:
+                n_empty += 1
+                assert raw.shape == (1, A) and float(raw.abs().max()) == 0.0          # the reference's empty sum
+                assert torch.equal(out[e], torch.zeros(A, dtype=torch.float64))      # bit-exact zeros, no NaN
+            else:
+                assert np.allclose(out[e].numpy(), raw.numpy()[0], rtol=0, atol=1e-13)
+    assert n_empty == 3
 
 
 @pytest.mark.parametrize("G,B,H,W,Cin,Cout", [(2, 2, 60, 80, 128, 128), (2, 3, 30, 40, 256, 256), (1, 2, 15, 20, 512, 512),

@@ -147,3 +147,52 @@ def test_weight_that_outgrows_its_scale_raises_the_weight_flag():
     eng.adamw_step(1e3, 1e3, 0.0, step=1)                  # absurd learning rate: |w| jumps by ~1e3 per element
     f = eng.read_flags()
     assert f & ACTEngine.FLAG_WEIGHT
+
+
+def test_adamw_update_is_skipped_on_the_device_after_a_non_finite_loss():
+    """the range-guard flags used to be read only every validate_every steps while the AdamW kernel
+    applied every update -- after the first non-finite loss NaN gradients went into the fp32 master weights and the Adam
+    moments for hundreds of steps.  Now the kernel reads the handle's flag word: an inf loss leaves parameters AND moments
+    untouched (shown by a following good step being bit-identical to the same step on a fresh engine)."""
+    cfg = tiny_config(kl_weight=1)
+    sd = W.generate_state_dict(cfg, seed=3)
+    inp = W.generate_inputs(cfg, 2, seed=9, with_actions=True)
+
+    def make():
+        e = ACTEngine(cfg, max_batch=2, training=True)
+        e.load_state_dict(sd)
+        e.finalize()
+        return e
+
+    def step(e, actions, t):
+        d = e.device
+        e.zero_grad()
+        out = e.forward_train(torch.from_numpy(inp["qpos"]).to(d), torch.from_numpy(inp["image_u8"]).to(d), actions.to(d),
+                              torch.from_numpy(inp["is_pad"]).to(d), eps=torch.from_numpy(inp["eps"]).to(d))
+        e.backward(1.0)
+        e.adamw_step(1e-3, 1e-4, 1e-4, step=t)
+        return out
+
+    good = torch.from_numpy(inp["actions"])
+    bad = good.clone()
+    bad[0, 0, 0] = float("inf")                      # l1 = inf -> ACTMI_FLAG_LOSS raised by the forward
+    eng = make()
+    before = eng.state_dict()
+    out = step(eng, bad, 1)
+    assert not np.isfinite(float(out["loss"]))
+    after = eng.state_dict()
+    for k in before:
+        assert torch.equal(before[k], after[k]), f"{k} changed although the step's loss was not finite"
+    with pytest.raises(FloatingPointError):
+        eng.check_flags()                            # the host check reports it (and clears the word)
+    # the skipped step left the moments alone: a good step now == the same good step on a fresh engine, bit for bit
+    step(eng, good, 1)
+    ref = make()
+    step(ref, good, 1)
+    a, b = eng.state_dict(), ref.state_dict()
+    moved = 0
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+        moved += int(not torch.equal(a[k], before[k]))
+    assert moved > 100                               # and the good step did update the parameters
+    eng.check_flags()
