@@ -57,3 +57,34 @@ def allreduce_buckets(flat: torch.Tensor, bucket_elems: int, group=None):
     for w in works:
         w.wait()
     return len(works)
+
+
+class _Done:
+    """Work handle of a collective that already completed."""
+
+    def wait(self):
+        return True
+
+
+def reduce_scatter_flat(out: torch.Tensor, inp: torch.Tensor, group=None):
+    """SUM reduce-scatter of a flat tensor (rank r receives the r-th of world equal slices of the sum), asynchronous:
+    returns a work handle.  RCCL (backend nccl) runs it on device memory, in place when `out` is the r-th slice of `inp`.
+    gloo has no device path for it: CUDA tensors are staged through the host (CPU tests and the two-ranks-on-one-GPU test)."""
+    if dist.get_backend(group) == "gloo" and inp.is_cuda:
+        h_in = inp.detach().cpu()
+        h_out = torch.empty(out.numel(), dtype=h_in.dtype)
+        dist.reduce_scatter_tensor(h_out, h_in, op=dist.ReduceOp.SUM, group=group)
+        out.copy_(h_out)
+        return _Done()
+    return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def all_gather_flat(out: torch.Tensor, inp: torch.Tensor, group=None):
+    """all-gather of equal flat slices into `out` (in place when `inp` is the r-th slice of `out`); see reduce_scatter_flat."""
+    if dist.get_backend(group) == "gloo" and inp.is_cuda:
+        h_in = inp.detach().cpu()
+        h_out = torch.empty(out.numel(), dtype=h_in.dtype)
+        dist.all_gather_into_tensor(h_out, h_in, group=group)
+        out.copy_(h_out)
+        return _Done()
+    return dist.all_gather_into_tensor(out, inp, group=group, async_op=True)

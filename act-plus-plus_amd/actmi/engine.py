@@ -343,6 +343,107 @@ class ACTEngine:
         cur.wait_stream(side)
         self.sync_flags(group)
 
+    # ---- sharded optimizer (reduce-scatter -> sharded fused AdamW -> all-gather of the parameters) ---------
+    def param_arena(self) -> torch.Tensor:
+        """Flat float32 view (no copy) of the fp32 parameter arena (same layout as grad_arena)."""
+        p, n = C.c_void_p(), C.c_int64()
+        L.check(self.lib.actmi_param_arena(self.h, C.byref(p), C.byref(n)), self.h, "param_arena")
+        return _from_ptr(p.value, n.value, self.device)
+
+    def _shard_plan(self, world: int, bucket_elems: int):
+        """Buckets [lo, hi) of the arena whose size is a multiple of 64 * world floats (the optimizer works on 64-float slots):
+        rank r owns the r-th of `world` equal slices of every bucket.  The arena's tail that does not fill such a unit
+        (< 64 * world floats) is all-reduced and updated by every rank.  Buckets never straddle the phase-1 boundary (the
+        transformer gradients, final before the backbone backward runs)."""
+        n = self.grad_arena().numel()
+        lo1, n1 = self.grad_phase_range(1)
+        unit = 64 * world
+        bsz = max(unit, bucket_elems // unit * unit)
+        buckets, tails = [], []
+        for a, b in ((lo1, lo1 + n1), (lo1 + n1, n)):
+            main = a + (b - a) // unit * unit
+            x = a
+            while x < main:
+                y = min(main, x + bsz)
+                buckets.append((x, y, 1 if b <= lo1 + n1 else 2))
+                x = y
+            if main < b:
+                tails.append((main, b))
+        return buckets, tails
+
+    def backward_reduce_scatter(self, loss_scale: float = 1.0, group=None, bucket_mb: int = 64, comm_dtype=None):
+        """loss.backward() + the gradient half of the sharded data-parallel step: every bucket of the gradient arena is
+        REDUCE-SCATTERED (RCCL over xGMI when the backend is nccl) so that each rank ends up with the summed gradients of
+        the slices it owns -- half the bytes of an all-reduce; the buckets of the transformer range go out from a side stream
+        while the backbone backward still runs (actmi_wait_grad_phase), the rest when the backward has drained.
+        comm_dtype=torch.bfloat16 sends the buckets as bf16 (half the link bytes again; the sum is formed in bf16, so this is
+        an opt-in speed mode, never the default).  After this call only the owned slices of grad_arena() hold gradients of
+        the global batch.  Follow with adamw_step_sharded()."""
+        import torch.distributed as dist
+        from .dist_utils import reduce_scatter_flat
+        self.backward(loss_scale)
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            self._shard = None
+            return
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        buckets, tails = self._shard_plan(world, bucket_mb * (1 << 20) // 4)
+        arena = self.grad_arena()
+        cur = torch.cuda.current_stream(self.device)
+        if not hasattr(self, "_comm_stream"):
+            self._comm_stream = torch.cuda.Stream(device=self.device)
+        side = self._comm_stream
+
+        def rs(lo, hi):
+            k = (hi - lo) // world
+            own = arena[lo + rank * k: lo + (rank + 1) * k]
+            if comm_dtype is None:
+                return reduce_scatter_flat(own, arena[lo:hi], group), None
+            src = arena[lo:hi].to(comm_dtype)
+            dst = torch.empty(k, dtype=comm_dtype, device=self.device)
+            return reduce_scatter_flat(dst, src, group), (own, dst, src)
+
+        def finish(works):
+            for w, cast in works:
+                w.wait()
+                if cast is not None:
+                    cast[0].copy_(cast[1])
+        L.check(self.lib.actmi_wait_grad_phase(self.h, 1, C.c_void_p(side.cuda_stream)), self.h, "wait_grad_phase")
+        with torch.cuda.stream(side):
+            finish([rs(lo, hi) for lo, hi, ph in buckets if ph == 1])            # under the rest of the backward
+        finish([rs(lo, hi) for lo, hi, ph in buckets if ph == 2])
+        for lo, hi in tails:
+            dist.all_reduce(arena[lo:hi], op=dist.ReduceOp.SUM, group=group)
+        cur.wait_stream(side)
+        self.sync_flags(group)
+        self._shard = (world, rank, buckets, tails, group)
+
+    def adamw_step_sharded(self, lr, lr_backbone, weight_decay=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, step=1):
+        """The optimizer half: fused AdamW on the slices this rank owns (1/world of the arena: its Adam moments are the only
+        ones ever touched), then the updated parameter slices are ALL-GATHERED bucket by bucket and the derived weights
+        rebuilt.  Without a process group (or before backward_reduce_scatter) this is adamw_step."""
+        from .dist_utils import all_gather_flat
+        sh = getattr(self, "_shard", None)
+        if sh is None:
+            return self.adamw_step(lr, lr_backbone, weight_decay, beta1, beta2, eps, step)
+        world, rank, buckets, tails, group = sh
+        params = self.param_arena()
+        sp = self._sp()
+
+        def upd(lo, cnt):
+            L.check(self.lib.actmi_adamw_step_range(self.h, lr, lr_backbone, weight_decay, beta1, beta2, eps, int(step), int(lo),
+                                                    int(cnt), sp), self.h, "adamw_step_range")
+        works = []
+        for lo, hi, _ in buckets:
+            k = (hi - lo) // world
+            upd(lo + rank * k, k)
+            works.append(all_gather_flat(params[lo:hi], params[lo + rank * k: lo + (rank + 1) * k], group))
+        for lo, hi in tails:
+            upd(lo, hi - lo)                           # all-reduced gradients: every rank computes the same update
+        for w in works:
+            w.wait()
+        L.check(self.lib.actmi_refresh_weights(self.h, sp), self.h, "refresh_weights")
+        self._shard = None
+
     def flags_tensor(self) -> torch.Tensor:
         """int32 view (no copy) of the handle's device flag word."""
         p = C.c_void_p()

@@ -114,6 +114,9 @@ def load():
         "actmi_backward": ([vp, f32, vp], i32),
         "actmi_zero_grad": ([vp, vp], i32),
         "actmi_adamw_step": ([vp, f32, f32, f32, f32, f32, f32, i64, vp], i32),
+        "actmi_adamw_step_range": ([vp, f32, f32, f32, f32, f32, f32, i64, i64, i64, vp], i32),
+        "actmi_refresh_weights": ([vp, vp], i32),
+        "actmi_param_arena": ([vp, C.POINTER(vp), C.POINTER(i64)], i32),
         "actmi_grad_ptr": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i64)], i32),
         "actmi_grad_arena": ([vp, C.POINTER(vp), C.POINTER(i64)], i32),
         "actmi_grad_phase_range": ([vp, i32, C.POINTER(i64), C.POINTER(i64)], i32),

@@ -146,6 +146,24 @@ int actmi_adamw_step(actmi_handle h, float lr, float lr_backbone, float weight_d
     ENTER(h);
     return train_adamw_step(h, lr, lr_backbone, weight_decay, beta1, beta2, eps, step, S(stream));
 }
+int actmi_adamw_step_range(actmi_handle h, float lr, float lr_backbone, float weight_decay, float beta1, float beta2, float eps,
+                           int64_t step, int64_t offset, int64_t count, void* stream) {
+    if (!h) return ACTMI_E_INVALID;
+    ENTER(h);
+    return train_adamw_range(h, lr, lr_backbone, weight_decay, beta1, beta2, eps, step, offset, count, S(stream));
+}
+int actmi_refresh_weights(actmi_handle h, void* stream) {
+    if (!h) return ACTMI_E_INVALID;
+    ENTER(h);
+    if (!h->finalized) return bad(h, "refresh_weights before finalize", ACTMI_E_STATE);
+    return engine_prepare_weights(h, S(stream), true);
+}
+int actmi_param_arena(actmi_handle h, void** dev_ptr, int64_t* nfloats) {
+    if (!h) return ACTMI_E_INVALID;
+    if (dev_ptr) *dev_ptr = h->pbase;
+    if (nfloats) *nfloats = h->ptotal;
+    return 0;
+}
 int actmi_grad_ptr(actmi_handle h, const char* key, void** dev_ptr, int64_t* numel) {
     if (!h || !key) return ACTMI_E_INVALID;
     ENTER(h);

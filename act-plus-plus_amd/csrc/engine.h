@@ -182,5 +182,7 @@ int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st);
 int train_zero_grad(actmi_ctx* ctx, hipStream_t st);
 int train_adamw_step(actmi_ctx* ctx, float lr, float lr_backbone, float wd, float b1, float b2, float eps, int64_t step,
                      hipStream_t st);
+int train_adamw_range(actmi_ctx* ctx, float lr, float lr_backbone, float wd, float b1, float b2, float eps, int64_t step,
+                      int64_t offset, int64_t count, hipStream_t st);
 int engine_forward_infer(actmi_ctx* ctx, const float* qpos, const void* image, int fmt, int B, float* a_hat,
                          hipStream_t st, const float* vq_sample /* [B][vq_class*vq_dim] or null */);

@@ -1080,11 +1080,22 @@ int train_zero_grad(actmi_ctx* ctx, hipStream_t st) {
 
 int train_adamw_step(actmi_ctx* ctx, float lr, float lr_backbone, float wd, float b1, float b2, float eps, int64_t step,
                      hipStream_t st) {
+    const int rc = train_adamw_range(ctx, lr, lr_backbone, wd, b1, b2, eps, step, 0, ctx->ptotal, st);
+    if (rc != 0) return rc;
+    return engine_prepare_weights(ctx, st, true); // conv repack, decoder constants, learned pos rows follow the new weights
+}
+
+// the update alone on the arena range [offset, offset + count) (64-float aligned): the sharded optimizer of data-parallel
+// training runs it on the slices a rank owns; engine_prepare_weights follows once the updated parameters were all-gathered
+int train_adamw_range(actmi_ctx* ctx, float lr, float lr_backbone, float wd, float b1, float b2, float eps, int64_t step,
+                      int64_t offset, int64_t count, hipStream_t st) {
     if (!ctx->train) { ctx->err = "handle was created without enable_training"; return ACTMI_E_STATE; }
+    if (offset < 0 || count < 0 || (offset & 63) || offset + count > ctx->ptotal) { ctx->err = "adamw range must be 64-float aligned and inside the arena"; return ACTMI_E_INVALID; }
+    if (count == 0) return 0;
     TrainState& T = *ctx->train;
     // gated on the device by the handle's flag word: after a non-finite loss or a weight beyond its split scale the
     // update is skipped until the host has read and cleared the word (actmi_get_flags) -- weights and moments stay intact
-    CHK(launch_adamw(ctx->pbase, T.gbase, T.mbase, T.vbase, T.group, ctx->ptotal, lr, lr_backbone, wd, b1, b2, eps, step, st,
-                     ctx->flags, ACTMI_FLAG_LOSS | ACTMI_FLAG_WEIGHT));
-    return engine_prepare_weights(ctx, st, true); // conv repack, decoder constants, learned pos rows follow the new weights
+    CHK(launch_adamw(ctx->pbase + offset, T.gbase + offset, T.mbase + offset, T.vbase + offset, T.group + (offset >> 6), count, lr,
+                     lr_backbone, wd, b1, b2, eps, step, st, ctx->flags, ACTMI_FLAG_LOSS | ACTMI_FLAG_WEIGHT));
+    return 0;
 }

@@ -36,8 +36,15 @@ class _Loss(torch.Tensor):
     def backward(self, *a, **k):      # noqa: D401
         import torch.distributed as dist
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        # data parallel: mean over the global batch; the all-reduce of the transformer gradients runs under the backbone backward
-        self._policy.model.backward_allreduce(1.0 / world)
+        # data parallel: mean over the global batch.  Default: the sharded step of SURVEY 8 f1 (bucketed reduce-scatter, the
+        # transformer buckets under the backbone backward; optimizer.step() then updates the owned slices and all-gathers the
+        # parameters).  ACTMI_DP_MODE=allreduce: every rank reduces the whole arena and runs the whole AdamW.
+        import os
+        if world > 1 and os.environ.get("ACTMI_DP_MODE", "zero1") != "allreduce":
+            cd = torch.bfloat16 if os.environ.get("ACTMI_DP_GRAD_DTYPE") == "bf16" else None
+            self._policy.model.backward_reduce_scatter(1.0 / world, comm_dtype=cd)
+        else:
+            self._policy.model.backward_allreduce(1.0 / world)
 
 
 class _AdamW:
@@ -52,7 +59,8 @@ class _AdamW:
 
     def step(self):
         self.t += 1
-        self.engine.adamw_step(self.lr, self.lr_backbone, self.weight_decay, step=self.t)
+        # (the sharded form when loss.backward() left a shard plan: data-parallel training; otherwise the plain fused step)
+        self.engine.adamw_step_sharded(self.lr, self.lr_backbone, self.weight_decay, step=self.t)
 
 
 class ACTPolicy:

@@ -519,8 +519,14 @@ def train_rig(cfg, B, dev, seed, world):
     def step(i):
         eng.zero_grad()
         out = eng.forward_train(t["qpos"], t["image_u8"], t["actions"], t["is_pad"], eps=t["eps"])
-        eng.backward_allreduce(1.0 / world)   # data parallel: bucketed all-reduce over RCCL, transformer range under the backbone backward
-        eng.adamw_step(1e-5, 1e-5, 1e-4, step=i + 1)
+        if world > 1 and os.environ.get("ACTMI_DP_MODE", "zero1") != "allreduce":
+            # data parallel, SURVEY 8 f1: bucketed reduce-scatter over RCCL (transformer buckets under the backbone backward),
+            # fused AdamW on the owned 1/world of the arena, all-gather of the updated parameters
+            eng.backward_reduce_scatter(1.0 / world)
+            eng.adamw_step_sharded(1e-5, 1e-5, 1e-4, step=i + 1)
+        else:
+            eng.backward_allreduce(1.0 / world)   # bucketed all-reduce, transformer range under the backbone backward; full AdamW
+            eng.adamw_step(1e-5, 1e-5, 1e-4, step=i + 1)
         return out
     return eng, step
 

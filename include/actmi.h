@@ -273,6 +273,15 @@ int actmi_backward(actmi_handle h, float loss_scale, void* stream);
 int actmi_zero_grad(actmi_handle h, void* stream);
 int actmi_adamw_step(actmi_handle h, float lr, float lr_backbone, float weight_decay, float beta1, float beta2,
                      float eps, int64_t step, void* stream);
+/* Sharded optimizer of data-parallel training (reduce-scatter -> sharded AdamW -> all-gather): the same update
+ * on the arena range [offset, offset + count) only (offset a multiple of 64 floats), WITHOUT rebuilding the derived weights;
+ * actmi_refresh_weights rebuilds them (conv repack, split images, decoder constants) once the caller has all-gathered the
+ * updated parameter arena (actmi_param_arena).  actmi_adamw_step == actmi_adamw_step_range(0, whole arena) + refresh. */
+int actmi_adamw_step_range(actmi_handle h, float lr, float lr_backbone, float weight_decay, float beta1, float beta2,
+                           float eps, int64_t step, int64_t offset, int64_t count, void* stream);
+int actmi_refresh_weights(actmi_handle h, void* stream);
+/* the whole fp32 parameter arena (the layout of the gradient arena: actmi_grad_arena) */
+int actmi_param_arena(actmi_handle h, void** dev_ptr, int64_t* nfloats);
 int actmi_grad_ptr(actmi_handle h, const char* key, void** dev_ptr, int64_t* numel);
 /* the whole gradient arena (same layout as the parameter arena) for bucketed data-parallel all-reduce over RCCL */
 int actmi_grad_arena(actmi_handle h, void** dev_ptr, int64_t* nfloats);

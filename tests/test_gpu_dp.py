@@ -82,3 +82,79 @@ def test_two_rank_data_parallel_equals_single_process_batch(tmp_path):
         assert moved > 0                                              # the step did change the weights
         # first AdamW step = lr * sign-like update: compare the UPDATES, tolerance a few % of the step size
         assert np.abs(a - b).max() <= 0.05 * moved + 1e-7, k
+
+
+# ---- sharded optimizer (SURVEY 8 f1: reduce-scatter -> sharded AdamW -> all-gather) and the RCCL-ready variant -------------
+def _rank_sharded(rank, world, port, outdir, backend):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                       "LOCAL_RANK": str(rank), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(os.path.dirname(here), "act-plus-plus_amd"), os.path.dirname(here)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from actmi.config import tiny_config
+    from actmi import weights as W
+    from actmi import dist_utils
+    from actmi.engine import ACTEngine
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)      # nccl: one GPU per rank; gloo: both ranks share the one GPU
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = tiny_config(kl_weight=1)
+    inp = W.generate_inputs(cfg, world, seed=31, with_actions=True)
+    t = {k: torch.from_numpy(v[rank:rank + 1]).to(dev) for k, v in inp.items()}
+
+    def run(mode, steps=2, comm_dtype=None):
+        eng = ACTEngine(cfg, max_batch=1, training=True, device=str(dev))
+        eng.load_state_dict(W.generate_state_dict(cfg, seed=5))
+        for i in range(steps):
+            eng.zero_grad()
+            eng.forward_train(t["qpos"], t["image_u8"], t["actions"], t["is_pad"], eps=t["eps"])
+            if mode == "allreduce":
+                eng.backward_allreduce(1.0 / world, bucket_mb=1)
+                eng.adamw_step(1e-3, 1e-4, 1e-4, step=i + 1)
+            else:
+                eng.backward_reduce_scatter(1.0 / world, bucket_mb=1, comm_dtype=comm_dtype)
+                assert eng._shard is not None and len(eng._shard[2]) >= 2            # several buckets, both phases
+                eng.adamw_step_sharded(1e-3, 1e-4, 1e-4, step=i + 1)
+        torch.cuda.synchronize(dev)
+        eng.check_flags()
+        a = eng.forward_infer(t["qpos"], t["image_u8"]).cpu()                        # derived weights follow the gathered arena
+        return eng.state_dict(), a
+
+    sd_a, out_a = run("allreduce")
+    sd_s, out_s = run("sharded")
+    for k in sd_a:
+        if world == 2:          # a + b == b + a in fp32: two ranks give the same bits on either path
+            assert torch.equal(sd_a[k], sd_s[k]), f"{k}: sharded optimizer differs from all-reduce + full AdamW"
+        else:
+            assert torch.allclose(sd_a[k], sd_s[k], rtol=0, atol=1e-6), k
+    assert torch.equal(out_a, out_s) if world == 2 else torch.allclose(out_a, out_s, atol=1e-5)
+    sd_b, _ = run("sharded", comm_dtype=torch.bfloat16)                              # opt-in bf16 gradient exchange
+    worst = max(float((sd_b[k] - sd_s[k]).abs().max()) for k in sd_s)
+    assert worst < 2.5e-3, worst                    # two lr = 1e-3 sign-like steps: bf16 sums may flip tiny gradients' updates
+    # the eval path's collective on this backend: every rank's id arrives, in rank order
+    ids = dist_utils.all_gather_rows(torch.full((1, 2), float(rank)), [1] * world)
+    assert ids[:, 0].tolist() == [float(r) for r in range(world)]
+    torch.save({k: v for k, v in sd_s.items()}, os.path.join(outdir, f"sharded_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_sharded_optimizer_equals_allreduce_step(tmp_path, backend):
+    """reduce-scatter -> AdamW on the owned slices -> all-gather of the parameters gives every rank the weights that
+    all-reduce + the full AdamW gives (bit for bit at two ranks).  'gloo': two ranks share the one GPU of the test box;
+    'nccl' (= RCCL over xGMI) runs when the box has two GPUs or more and exercises all_gather_rows, the overlapped
+    reduce-scatter and the flag exchange on the backend the multi-GPU bench uses (VERDICT r02 weak #13)."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank: this box has a single GPU (the gloo variant covers the same code path)")
+    world = 2
+    mp.spawn(_rank_sharded, args=(world, 29950 + os.getpid() % 40 + (0 if backend == "gloo" else 50), str(tmp_path), backend),
+             nprocs=world, join=True)
+    a = torch.load(tmp_path / "sharded_rank0.pt", weights_only=True)
+    b = torch.load(tmp_path / "sharded_rank1.pt", weights_only=True)
+    assert all(torch.equal(a[k], b[k]) for k in a)                                  # the replicas stay identical
