@@ -48,6 +48,8 @@ class GemmDesc(C.Structure):
         ("epi", C.c_int32), ("epi_scale", C.c_float), ("epi_row", C.c_void_p), ("gRow", C.c_int64), ("gRow2", C.c_int64),
         ("epi_colkill", C.c_void_p), ("gColkill", C.c_int64), ("tile_hint", C.c_int32),
         ("finite_flag", C.c_void_p), ("finite_bit", C.c_uint32),
+        ("Ax", C.c_void_p), ("kx_begin", C.c_int32), ("Hx", C.c_int32), ("Wx", C.c_int32), ("Cx", C.c_int32),
+        ("stride_x", C.c_int32), ("gAx", C.c_int64),
     ]
 
 

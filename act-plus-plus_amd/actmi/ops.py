@@ -171,6 +171,47 @@ def gemm16(A16, W16, alpha=1.0, bias=None, scale=None, res=None, res_fmt="s16", 
     return out
 
 
+def conv2d_with_second_source(y1, x, wf_split, w_scale, bias, stride_x=2, relu=True, splitk=0):
+    """A ResNet block's conv2 with the block's 1x1 / stride-2 downsample branch in the same contraction (gemm.hip second
+    source): y1 [G,B,H,W,C] is convolved 3x3 / s1 / p1, x [G,B,Hx,Wx,Cx] joins at stride_x as extra columns of the contraction.
+    wf_split: split16 image (built with w_scale) of [G][Cout][9*C + Cx]; bias [G,Cout].  f16x3 only.  Returns [G,B,H,W,Cout]."""
+    lib = L.load()
+    G, B, H, W, Cc = y1.shape
+    _, _, Hx, Wx, Cx = x.shape
+    Cout = wf_split.shape[1]
+    Kf = 9 * Cc + Cx
+    assert wf_split.numel() == G * Cout * Kf
+    M = B * H * W
+
+    def desc(C_ptr, ldc, gC):
+        d = L.GemmDesc()
+        d.A, d.mode = y1.data_ptr(), 1
+        d.H, d.W, d.Cin, d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo = H, W, Cc, 3, 3, 1, 1, H, W
+        d.img_stride = H * W * Cc
+        d.Ax, d.kx_begin, d.Hx, d.Wx, d.Cx, d.stride_x, d.gAx = x.data_ptr(), 9 * Cc, Hx, Wx, Cx, stride_x, B * Hx * Wx * Cx
+        d.Bw, d.ldb = wf_split.data_ptr(), Kf
+        d.C, d.ldc = C_ptr, ldc
+        d.M, d.N, d.K, d.groups = M, Cout, Kf, G
+        d.gA, d.gB, d.gSB, d.gC = B * H * W * Cc, Cout * Kf, Cout, gC
+        d.prec, d.b_split, d.b_scale = PREC["f16x3"], 1, float(w_scale)
+        return d
+    out = torch.empty((G, B, H, W, Cout), dtype=torch.float32, device=y1.device)
+    if splitk and splitk > 1:
+        part = torch.empty((G, splitk, M, Cout), dtype=torch.float32, device=y1.device)
+        d = desc(part.data_ptr(), Cout, splitk * M * Cout)
+        d.splitk, d.split_stride = int(splitk), M * Cout
+        L.check(lib.actmi_op_gemm(C.byref(d), L.current_stream_ptr()), None, "op_gemm(conv + second source, split)")
+        for g in range(G):
+            L.check(lib.actmi_op_splitk_combine(part[g].data_ptr(), int(splitk), M * Cout, Cout, M, Cout, None, _p(bias[g]), None, 0,
+                                                1 if relu else 0, out[g].data_ptr(), Cout, L.current_stream_ptr()), None, "combine")
+        return out
+    d = desc(out.data_ptr(), Cout, M * Cout)
+    d.bias = bias.data_ptr()
+    d.relu = 1 if relu else 0
+    L.check(lib.actmi_op_gemm(C.byref(d), L.current_stream_ptr()), None, "op_gemm(conv + second source)")
+    return out
+
+
 def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1, pad=1, prec=None, w_split=False, b_scale=0.0):
     """x [G,B,H,W,Cin] camera-major NHWC; w_ohwi [G,Cout,KH,KW,Cin]; scale/bias [G,Cout]; returns [G,B,Ho,Wo,Cout]."""
     lib = L.load()

@@ -31,6 +31,12 @@ struct ConvLayer {
     float w16_scale = W16_SCALE;
     float* scale = nullptr;   // [cam][cout]
     float* bias = nullptr;
+    // conv2 of a block with a downsample branch (inference, f16x3): the branch rides in this convolution's contraction
+    // (gemm.hip second source).  wf = [cam][cout][K + Kx] = [scale * w | ds.scale * ds.w] (FrozenBN folded), bias_f = bias + ds.bias
+    int ds_index = -1;        // index of the block's downsample layer in ctx->convs, or -1
+    int Kx = 0;               // = ds.cin
+    float *wf = nullptr, *wf16 = nullptr, *bias_f = nullptr;
+    float wf16_scale = W16_SCALE;
 };
 
 struct MhaW { float *in_w, *in_b, *out_w, *out_b; };
@@ -129,6 +135,7 @@ struct actmi_ctx {
     int ln_split = 3;                  // split factor of a long-K product followed by a slice-summing LayerNorm (ACTMI_LN_SPLIT)
     int last_B = 0;                    // batch of the forward in flight (debug views)
     int policy_mult = 1;               // split-K policy counts the tiles of the WHOLE camera set while a half is being launched
+    bool fuse_ds = true;               // downsample branch inside conv2's contraction (ACTMI_FUSE_DS=0: three launches as before)
     bool conv_direct = false;          // layer2-4 stride-1 3x3 convolutions on the direct kernel (conv3g.hip): measured slower, opt-in
     int conv_direct_min_images = 8;    // below this many images (cameras x batch) its grid is too small: implicit GEMM + split-K
     int64_t ptotal = 0;

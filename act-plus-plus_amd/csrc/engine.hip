@@ -167,10 +167,14 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half, LnFuse* ln
             a.Bw = ctx->p16base + (a.Bw - ctx->pbase);
             a.b_split = 1;
         } else {
-            for (const ConvLayer& cl : ctx->convs)
+            for (const ConvLayer& cl : ctx->convs) {
                 if (a.Bw >= cl.w && a.Bw < cl.w + (int64_t)ctx->cfg.num_cams * cl.cout * cl.K) {     // (a camera's slice of it)
                     a.Bw = cl.w16 + (a.Bw - cl.w); a.b_split = 1; a.b_scale = cl.w16_scale; break;
                 }
+                if (cl.wf && a.Bw >= cl.wf && a.Bw < cl.wf + (int64_t)ctx->cfg.num_cams * cl.cout * (cl.K + cl.Kx)) {
+                    a.Bw = cl.wf16 + (a.Bw - cl.wf); a.b_split = 1; a.b_scale = cl.wf16_scale; break;
+                }
+            }
         }
     }
     // Small grids (B = 1-4 rollouts: layer3/4 convolutions, the K = 3200 FFN products): a launch of a few hundred tiles
@@ -467,8 +471,21 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
                 cin = cout; H = c1.Ho; W = c1.Wo;
             }
         }
+        for (auto& cl : ctx->convs) cl.K = cl.k * cl.k * cl.cin;
+        // conv2 of every block with a downsample branch carries the branch in its own contraction (inference, f16x3)
+        for (size_t i = 0; i + 2 < ctx->convs.size(); ++i) {
+            ConvLayer& k2 = ctx->convs[i + 1];
+            const ConvLayer& ds = ctx->convs[i + 2];
+            if (ds.k == 1 && ds.stride == 2 && k2.k == 3 && k2.stride == 1 && ds.cout == k2.cout && ds.Ho == k2.Ho && ds.Wo == k2.Wo &&
+                ds.name.find("downsample") != std::string::npos && (k2.cin % 32) == 0 && (ds.cin % 32) == 0) {
+                k2.ds_index = (int)i + 2;
+                k2.Kx = ds.cin;
+                if ((rc = dev_alloc(ctx, &k2.wf, (int64_t)C * k2.cout * (k2.K + k2.Kx)))) return fail(rc);
+                if ((rc = dev_alloc(ctx, &k2.wf16, (int64_t)C * k2.cout * (k2.K + k2.Kx)))) return fail(rc);
+                if ((rc = dev_alloc(ctx, &k2.bias_f, (int64_t)C * k2.cout))) return fail(rc);
+            }
+        }
         for (auto& cl : ctx->convs) {
-            cl.K = cl.k * cl.k * cl.cin;
             if ((rc = dev_alloc(ctx, &cl.w, (int64_t)C * cl.cout * cl.K))) return fail(rc);
             if ((rc = dev_alloc(ctx, &cl.w16, (int64_t)C * cl.cout * cl.K))) return fail(rc);
             if ((rc = dev_alloc(ctx, &cl.scale, (int64_t)C * cl.cout))) return fail(rc);
@@ -525,6 +542,7 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
         // implicit GEMM at 128-512 channels (B = 8: 187 / 203 / 251 us against 173 / 188 / 214 us per launch,
         // profiles/r02_conv_direct_ab.json): re-staging the patch for every 64-channel chunk costs as much as the chunk's
         // nine taps of MFMAs.  Off unless ACTMI_CONV_DIRECT=1.
+        { const char* ef = getenv("ACTMI_FUSE_DS"); ctx->fuse_ds = !(ef && ef[0] == '0'); }
         const char* e3 = getenv("ACTMI_CONV_DIRECT");
         ctx->conv_direct = e3 && e3[0] == '1';
         if (const char* e4 = getenv("ACTMI_CONV_DIRECT_MIN_IMAGES")) ctx->conv_direct_min_images = atoi(e4);
@@ -611,6 +629,16 @@ int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st, bool after_step) {
         CHK(launch_conv1_wimg(ctx->conv1_w, ctx->conv1_wimg, C, w0, st, ctx->conv1_wscale));
         for (const ConvLayer& cl : ctx->convs)
             CHK(launch_split16(cl.w, cl.w16, (int64_t)C * cl.cout * cl.K, cl.w16_scale, st, ctx->flags));
+        // blocks with a downsample branch: [bn2.scale * conv2.w | bn_ds.scale * ds.w] and the summed bias (FrozenBN statistics
+        // are buffers: only the weights change under training, so the fold is redone with them)
+        for (const ConvLayer& cl : ctx->convs)
+            if (cl.wf) {
+                const ConvLayer& ds = ctx->convs[cl.ds_index];
+                CHK(launch_fold_cat_w(cl.w, cl.scale, cl.bias, ds.w, ds.scale, ds.bias, cl.wf, cl.bias_f, C, cl.cout, cl.K, cl.Kx, st));
+                // (at finalize the scale is measured right after this and the image split again: no overflow report from the
+                // provisional one)
+                CHK(launch_split16(cl.wf, cl.wf16, (int64_t)C * cl.cout * (cl.K + cl.Kx), cl.wf16_scale, st, after_step ? ctx->flags : nullptr));
+            }
     }
     // learned rows of the token position table (transformer.py:91-92)
     HIPCHK(hipMemcpyAsync(ctx->pos_tokens, ctx->P("additional_pos_embed.weight"), 2 * D * sizeof(float),
@@ -671,6 +699,30 @@ int engine_finalize(actmi_ctx* ctx, hipStream_t st) {
     }
     CHK(engine_calibrate_weight_scales(ctx, st));
     CHK(engine_prepare_weights(ctx, st));
+    if (ctx->gemm_prec == ACTMI_PREC_F16X3) {
+        // range guard of the fused conv2 + downsample images: FrozenBN scales are folded into those weights, so their magnitude
+        // is only known now -- measure each fused matrix on the device (max|w| * scale in [2^13, 2^14), capped at 2^12 like every
+        // other image) and split again with that scale; training keeps it and raises ACTMI_FLAG_WEIGHT on overflow
+        std::vector<ConvLayer*> fl;
+        for (auto& cl : ctx->convs) if (cl.wf) fl.push_back(&cl);
+        if (!fl.empty() && 2 * fl.size() <= (size_t)(4 * ctx->cfg.hidden_dim)) {
+            HIPCHK(hipMemsetAsync(ctx->tmp_vec, 0, 2 * fl.size() * sizeof(float), st));
+            for (size_t i = 0; i < fl.size(); ++i) {
+                const int64_t Kf = fl[i]->K + fl[i]->Kx;
+                CHK(launch_pow2_scale(fl[i]->wf, Kf, ctx->cfg.num_cams * fl[i]->cout, (int)Kf, ctx->tmp_vec + 2 * i, st));
+            }
+            std::vector<float> sc(2 * fl.size());
+            HIPCHK(hipMemcpyAsync(sc.data(), ctx->tmp_vec, sc.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (size_t i = 0; i < fl.size(); ++i) {
+                float v = sc[2 * i];
+                if (!(v > 0.f) || !(v <= 3.0e38f)) { ctx->err = "fused weights of " + fl[i]->name + " are not finite"; return ACTMI_E_INVALID; }
+                fl[i]->wf16_scale = v < 4096.f ? v : 4096.f;
+                CHK(launch_split16(fl[i]->wf, fl[i]->wf16, (int64_t)ctx->cfg.num_cams * fl[i]->cout * (fl[i]->K + fl[i]->Kx),
+                                   fl[i]->wf16_scale, st, ctx->flags));
+            }
+        }
+    }
     HIPCHK(hipStreamSynchronize(st));
     ctx->finalized = true;
     return 0;
@@ -809,13 +861,39 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
         auto run_conv = [&](const ConvLayer& cl, const float* in, float* out, const float* res, int relu) -> int {
             return run_conv_on(cl, in, out, res, relu, ls, c0, nc, half);
         };
+        // conv2 of a downsample block with the branch in its contraction: y = relu([W2' | Wd'] [y1 taps ; x at stride 2] + b)
+        auto run_conv_fused = [&](const ConvLayer& cl, const float* y1, const float* x, float* out) -> int {
+            const ConvLayer& ds = ctx->convs[cl.ds_index];
+            const int Kf = cl.K + cl.Kx;
+            GemmArgs a;
+            memset(&a, 0, sizeof(a));
+            a.mode = 1;
+            a.A = y1; a.H = cl.H; a.W = cl.W; a.Cin = cl.cin; a.KH = a.KW = cl.k; a.stride = cl.stride; a.pad = cl.pad;
+            a.Ho = cl.Ho; a.Wo = cl.Wo; a.img_stride = (int64_t)cl.H * cl.W * cl.cin;
+            a.M = B * cl.Ho * cl.Wo; a.N = cl.cout; a.K = Kf;
+            a.Ax = x; a.kx_begin = cl.K; a.Hx = ds.H; a.Wx = ds.W; a.Cx = ds.cin; a.stride_x = ds.stride;
+            a.gAx = (int64_t)B * ds.H * ds.W * ds.cin;
+            a.Bw = cl.wf + (int64_t)c0 * cl.cout * Kf; a.ldb = Kf; a.bias = cl.bias_f + (int64_t)c0 * cl.cout; a.relu = 1;
+            a.C = out; a.ldc = cl.cout;
+            a.groups = nc;
+            a.gA = (int64_t)B * cl.H * cl.W * cl.cin; a.gB = (int64_t)cl.cout * Kf; a.gSB = cl.cout;
+            a.gC = (int64_t)a.M * cl.cout;
+            return ctx_gemm(ctx, a, ls, half);
+        };
         size_t ci = 0;
         for (int li = 1; li <= 4; ++li) {
             for (int bi = 0; bi < 2; ++bi) {
                 const ConvLayer& k1 = ctx->convs[ci++];
                 const ConvLayer& k2 = ctx->convs[ci++];
                 const bool has_ds = (bi == 0 && li > 1);
-                if (has_ds) {
+                if (has_ds && ctx->fuse_ds && k2.wf && ctx->gemm_prec == ACTMI_PREC_F16X3) {
+                    // the downsample branch rides in conv2's contraction (second source = the block input at stride 2):
+                    // two launches instead of three, and the branch's map is neither written nor read back
+                    ++ci;                                        // (the downsample layer's own entry)
+                    CHK(run_conv(k1, cur, s1, nullptr, 1));
+                    CHK(run_conv_fused(k2, s1, cur, s2));
+                    std::swap(cur, s2);                          // x stays live until conv2 has read it: the output goes to s2
+                } else if (has_ds) {
                     const ConvLayer& ds = ctx->convs[ci++];
                     if (fork_ds) {
                         // the 1x1 / stride-2 downsample (23-50 us, HBM bound, few workgroups) only needs the block input: it

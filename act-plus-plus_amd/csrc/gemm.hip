@@ -65,7 +65,12 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 // UNMASKED (f16x3, forward operand forms only): the loop flavour without zero-fill selects and operand pre-scales is
 // its own instantiation -- as a block-uniform branch inside one kernel both flavours shared one register allocation and the
 // hot one spilled (A_N: 184 bytes of scratch per lane, A_NADD: 104)
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC, int BSPLIT, int UNMASKED>
+// XS (A_CONV only): the contraction continues past the filter taps into a SECOND source tensor -- a 1x1 / stride_x convolution
+// of Ax (NHWC, Cx channels) whose weights are the columns k >= kx_begin of the same B rows.  This is how the downsample branch
+// of a ResNet block (1x1 / s2 convolution + FrozenBN of the block input, torchvision BasicBlock as used at backbone.py:66-71)
+// rides inside the block's second 3x3 convolution: out = relu(W2' * y1 + Wd' * x_strided + (b2 + bd)) with the FrozenBN scales
+// folded into W2' / Wd' -- one launch and no residual round trip instead of three launches.
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC, int BSPLIT, int UNMASKED, int XS = 0>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128 * 64 && (AMODE == 0 /*A_N*/ || AMODE == 3 /*A_T*/) && !(AMODE == 0 && BMODE == 1)) ? 3 : 2)
     void gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;      // 256 threads (4 waves) or 512 (8 waves, 2 per SIMD) for the 256x128 tile
@@ -170,6 +175,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                            (int64_t)p.H * p.W * p.Cin < ((int64_t)1 << 30);
     unsigned a_tapmask[AMODE == A_CONV ? NLA : 1];
     int a_off0[AMODE == A_CONV ? NLA : 1];
+    int a_offx[XS ? NLA : 1];                   // XS: this row's pixel of the second source (floats from Axg), + cidx * 4
+    const float* __restrict__ Axg = XS ? p.Ax + (int64_t)g * p.gAx : nullptr;
+    const int ktx = XS ? p.kx_begin / BK : 0x7fffffff;      // first K tile of the second source
     const float conv_inv_tpr = (AMODE == A_CONV && conv_fast) ? 1.0f / (float)(p.Cin / BK) : 0.f;
     const float conv_inv_kw = (AMODE == A_CONV || AMODE == A_DGRAD) ? 1.0f / (float)p.KW : 0.f;
     const int dg_cq = (AMODE == A_DGRAD) ? p.K / (p.KH * p.KW) : BK;
@@ -214,6 +222,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                     const unsigned rowsel = (unsigned)((((uint64_t)1 << (r_hi * p.KW)) - 1u) & ~(((uint64_t)1 << (r_lo * p.KW)) - 1u));
                     a_tapmask[i] = a_ok[i] ? (rowsel & (colmask * conv_rep)) : 0u;
                     a_off0[i] = (a_hi0[i] * p.W + a_wi0[i]) * p.Cin + cidx * 4;
+                    if (XS) a_offx[i] = ((b * p.Hx + ho * p.stride_x) * p.Wx + wo * p.stride_x) * p.Cx + cidx * 4;
                 }
             } else {   // A_DGRAD: rows are input pixels (b, hi, wi)
                 const int hw = p.H * p.W;
@@ -287,6 +296,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                     R.ra[i] = ld4(a_ptr[i] + kc);
                     if (AMODE == A_NADD) R.rx[i] = ld4(add_ptr[i] + kc);
                     R.ra_ok[i] = a_ok[i] && kok;
+                }
+            } else if (XS && kt >= ktx) {
+                // second source (block-uniform): one tap, no padding -- every valid row reads Cx contiguous channels
+                const int dk = (kt - ktx) * BK;
+#pragma unroll
+                for (int i = 0; i < NLA; ++i) {
+                    R.ra[i] = ld4(Axg + (a_ok[i] ? a_offx[i] + dk : 0));
+                    R.ra_ok[i] = a_ok[i];
                 }
             } else if (AMODE == A_CONV && conv_fast) {
                 // uniform tap of this K tile (small exact integer divisions via reciprocal multiply: kt < 2^20)
@@ -901,12 +918,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
     if (stamp && threadIdx.x == 0) stamp[3] = __builtin_amdgcn_s_memtime();
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC, int BSPLIT, int UNMASKED>
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC, int BSPLIT, int UNMASKED, int XS = 0>
 int launch_cfg_u(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     static const int lds_pad = getenv("ACTMI_GEMM_LDSPAD") ? atoi(getenv("ACTMI_GEMM_LDSPAD")) : 0;   // tuning aid
     const int smem = 2 * stage_f4<BM, BN, PREC>() * 16 + lds_pad;
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, UNMASKED>;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, UNMASKED, XS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -921,13 +938,13 @@ int launch_cfg_u(const GemmArgs& a, hipStream_t st) {
         // ACTMI_PROF_SHAPES=1: one profile class per distinct launch shape (bench.py --shapes: the per-shape table)
         static const bool by_shape = getenv("ACTMI_PROF_SHAPES") && getenv("ACTMI_PROF_SHAPES")[0] == '1';
         if (by_shape)
-            snprintf(nm, sizeof(nm), "gemm_%s_kernel<%d,%d,%d,%d,%d,%d>[M=%d,N=%d,K=%d,g=%d,sk=%d,wgs=%d]", PREC ? "f16x3" : "f32",
-                     BM, BN, WM, WN, AMODE, BMODE, a.M, a.N, a.K, a.groups, splitk, tiles_m * tiles_n * a.groups * splitk);
+            snprintf(nm, sizeof(nm), "gemm_%s_kernel<%d,%d,%d,%d,%d,%d%s>[M=%d,N=%d,K=%d,g=%d,sk=%d,wgs=%d]", PREC ? "f16x3" : "f32",
+                     BM, BN, WM, WN, AMODE, BMODE, XS ? ",xs" : "", a.M, a.N, a.K, a.groups, splitk, tiles_m * tiles_n * a.groups * splitk);
         else
-            snprintf(nm, sizeof(nm), "gemm_%s_kernel<%d,%d,%d,%d,%d,%d>", PREC ? "f16x3" : "f32", BM, BN, WM, WN, AMODE, BMODE);
+            snprintf(nm, sizeof(nm), "gemm_%s_kernel<%d,%d,%d,%d,%d,%d%s>", PREC ? "f16x3" : "f32", BM, BN, WM, WN, AMODE, BMODE, XS ? ",xs" : "");
         const double g = a.groups;
         double abytes;
-        if (AMODE == A_CONV) abytes = (double)(a.M / (a.Ho * a.Wo)) * a.H * a.W * a.Cin;
+        if (AMODE == A_CONV) abytes = (double)(a.M / (a.Ho * a.Wo)) * a.H * a.W * a.Cin + (XS ? (double)a.M * a.Cx : 0.0);
         else if (AMODE == A_DGRAD) abytes = (double)(a.M / (a.H * a.W)) * a.Ho * a.Wo * (a.K / (a.KH * a.KW));
         else abytes = (double)a.M * a.K;
         const double bbytes = (BMODE == B_WGRAD) ? (double)(a.K / (a.Ho * a.Wo)) * a.H * a.W * a.Cin : (double)a.N * a.K;
@@ -945,8 +962,14 @@ int launch_cfg_b(const GemmArgs& a, hipStream_t st) {
     if constexpr (HOT) {
         const bool one_a = (a.a_scale == 0.f || a.a_scale == 1.f) && !a.a_scale_dev;
         const bool one_b = BSPLIT || ((a.b_scale == 0.f || a.b_scale == 1.f) && !a.b_scale_dev);
-        if ((a.K % BK) == 0 && one_a && one_b && a.epi == 0 && !a.amax_out && !a.finite_flag) return launch_cfg_u<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, 1>(a, st);
+        const bool unmasked_ok = (a.K % BK) == 0 && one_a && one_b && a.epi == 0 && !a.amax_out && !a.finite_flag;
+        if constexpr (AMODE == A_CONV && BSPLIT == 1) {
+            // second-source form: only built for the hot (unmasked, pre-split weights) flavour; launch_gemm has checked the rest
+            if (a.Ax) return unmasked_ok ? launch_cfg_u<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, 1, 1>(a, st) : -1001;
+        }
+        if (unmasked_ok) return launch_cfg_u<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, 1>(a, st);
     }
+    if (a.Ax) return -1001;              // no instantiation carries a second source in this precision / operand form
     return launch_cfg_u<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, 0>(a, st);
 }
 
@@ -1042,7 +1065,14 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t st, std::string* err) {
         } else if (a.mode == 1) {
             if (a.K & 3) return fail("K must be a multiple of 4");
             if (a.Cin & 3) return fail("Cin must be a multiple of 4");
-            if (a.K != a.KH * a.KW * a.Cin) return fail("K != KH*KW*Cin");
+            if (a.Ax) {
+                if (a.kx_begin != a.KH * a.KW * a.Cin || a.K != a.kx_begin + a.Cx) return fail("second source: K must be KH*KW*Cin + Cx, kx_begin = KH*KW*Cin");
+                if ((a.Cin % BK) || (a.Cx % BK) || a.KH * a.KW > 32) return fail("second source: Cin and Cx must be multiples of 32");
+                if (a.stride_x < 1 || (a.Ho - 1) * a.stride_x >= a.Hx || (a.Wo - 1) * a.stride_x >= a.Wx) return fail("second source: the strided pixel grid leaves the map");
+                const int64_t nimg = a.M / ((int64_t)a.Ho * a.Wo);
+                if (nimg * a.Hx * a.Wx * a.Cx >= ((int64_t)1 << 31) || (int64_t)a.H * a.W * a.Cin >= ((int64_t)1 << 30)) return fail("second source: map too large for 32-bit offsets");
+                if ((uintptr_t)a.Ax & 15) return fail("second source must be 16-byte aligned");
+            } else if (a.K != a.KH * a.KW * a.Cin) return fail("K != KH*KW*Cin");
             if (a.A_add || a.a_rowmap) return fail("addend not supported in conv mode");
             if (a.M % (a.Ho * a.Wo)) return fail("M must be images*Ho*Wo");
             amode = A_CONV;
@@ -1085,6 +1115,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t st, std::string* err) {
     else return fail("operand form combination not instantiated");
     if (prec == ACTMI_PREC_F16X3) { ACTMI_DISPATCH(PREC_F16X3) } else { ACTMI_DISPATCH(PREC_F32) }
 #undef ACTMI_DISPATCH
+    if (rc == -1001) return fail("a second source (Ax) needs prec f16x3, pre-split weights (b_split), K % 32 == 0 and a plain epilogue");
     if (rc != 0 && err) *err = std::string("gemm launch: ") + hipGetErrorString((hipError_t)rc);
     return rc == 0 ? 0 : -3;
 }

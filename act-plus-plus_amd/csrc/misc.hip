@@ -561,6 +561,30 @@ int launch_bn_fold(const float* w, const float* b, const float* rm, const float*
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// Weight matrix of a ResNet block's second convolution with the block's downsample branch riding in the same contraction
+// (gemm.hip, second source): out[g][n][:] = [ s2[g][n] * w2[g][n][0..K2) | sd[g][n] * wd[g][n][0..Kd) ], bias[g][n] = b2 + bd.
+// The FrozenBN scales are folded into the weights because the two convolutions share one accumulator (reference:
+// out = relu(bn2(conv2(y1)) + bn_ds(conv_ds(x))), torchvision BasicBlock as used at backbone.py:66-71).
+__global__ void fold_cat_w_kernel(const float* __restrict__ w2, const float* __restrict__ s2, const float* __restrict__ b2,
+                                  const float* __restrict__ wd, const float* __restrict__ sd, const float* __restrict__ bd,
+                                  float* __restrict__ out, float* __restrict__ bias, int N, int K2, int Kd, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int Kf = K2 + Kd;
+    const int k = (int)(idx % Kf);
+    const int64_t gn = idx / Kf;                  // g * N + n
+    out[idx] = k < K2 ? w2[gn * K2 + k] * s2[gn] : wd[gn * Kd + (k - K2)] * sd[gn];
+    if (k == 0) bias[gn] = b2[gn] + bd[gn];
+}
+
+int launch_fold_cat_w(const float* w2, const float* s2, const float* b2, const float* wd, const float* sd, const float* bd,
+                      float* out, float* bias, int G, int N, int K2, int Kd, hipStream_t st) {
+    const int64_t total = (int64_t)G * N * (K2 + Kd);
+    hipLaunchKernelGGL(fold_cat_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w2, s2, b2, wd, sd, bd, out, bias,
+                       N, K2, Kd, total);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 int launch_build_rowmap(int* map, int B, int C, int fh, int fw, int N, hipStream_t st) {
     const int total = C * B * fh * fw;
     hipLaunchKernelGGL(build_rowmap_kernel, dim3((total + 255) / 256), dim3(256), 0, st, map, B, C, fh, fw, N);

@@ -161,6 +161,14 @@ typedef struct actmi_gemm_desc {
      * guard rides on the last product of the forward instead of a pass of its own) */
     uint32_t* finite_flag;
     uint32_t finite_bit;
+    /* mode 1 only, optional SECOND SOURCE of the contraction: for k >= kx_begin (= KH*KW*Cin)
+     * A'[m = (img, ho, wo)][k] = Ax[img][ho * stride_x][wo * stride_x][k - kx_begin], Ax an NHWC map [img][Hx][Wx][Cx], K = kx_begin
+     * + Cx; Bw rows carry the matching Cx extra columns.  A ResNet block's 1x1 / stride-2 downsample convolution (+ FrozenBN,
+     * folded into the weights) rides in its second 3x3 convolution this way (torchvision BasicBlock, backbone.py:66-71).
+     * Needs prec f16x3, b_split, Cin % 32 == 0, Cx % 32 == 0, no operand pre-scales / fused epilogues; gAx = group stride. */
+    const float* Ax;
+    int32_t kx_begin, Hx, Wx, Cx, stride_x;
+    int64_t gAx;
 } actmi_gemm_desc;
 
 /* GEMM / implicit-GEMM convolution on PRE-SPLIT operands (the inference path's form of actmi_gemm_desc with prec f16x3;

@@ -428,3 +428,34 @@ def test_wgrad7x7s2_matches_torch(G, B, H, W):
         assert rel_err(got[c], exp) < 2e-6
     assert torch.equal(got_s, got * 2.0 ** -20)
     assert torch.equal(got, ops.wgrad7x7s2(dy.to(dev()), x.to(dev())).cpu())
+
+
+@pytest.mark.parametrize("G,B,H,W,Cc,Cx,Cout,splitk", [(2, 2, 15, 20, 64, 32, 64, 0), (1, 3, 30, 40, 128, 64, 128, 0),
+                                                       (2, 1, 8, 12, 256, 128, 256, 0), (1, 1, 15, 20, 512, 256, 512, 4),
+                                                       (1, 2, 7, 9, 64, 32, 96, 2)])
+def test_conv2_with_downsample_as_second_source(G, B, H, W, Cc, Cx, Cout, splitk):
+    """relu(bn2(conv3x3(y1)) + bn_ds(conv1x1_s2(x))) of a torchvision BasicBlock (reference backbone.py:66-71) as ONE implicit
+    GEMM whose contraction continues from the nine taps of y1 into the strided pixels of x, FrozenBN scales folded into the
+    weights; against torch's conv2d in float64.  Odd map sizes (x is (2H-1) x (2W-1) or 2H x 2W), several tile shapes, and the
+    sliced split-K form the engine uses at small batch."""
+    g = torch.Generator().manual_seed(G * 100 + H)
+    d = dev()
+    Hx, Wx = 2 * H - (H % 2), 2 * W - (W % 2)                # both parities of the stride-2 input size
+    y1 = torch.randn(G, B, Cc, H, W, generator=g)
+    x = torch.randn(G, B, Cx, Hx, Wx, generator=g)
+    w2 = torch.randn(G, Cout, Cc, 3, 3, generator=g) / (9 * Cc) ** 0.5
+    wd = torch.randn(G, Cout, Cx, 1, 1, generator=g) / Cx ** 0.5
+    s2, sd = torch.rand(G, Cout, generator=g) + 0.5, torch.rand(G, Cout, generator=g) * 2 + 0.1
+    b2, bd = torch.randn(G, Cout, generator=g) * 0.1, torch.randn(G, Cout, generator=g) * 0.1
+    exp = torch.stack([torch.relu(F.conv2d(y1[i].double(), w2[i].double(), None, 1, 1) * s2[i].double().view(1, -1, 1, 1)
+                                  + b2[i].double().view(1, -1, 1, 1)
+                                  + F.conv2d(x[i].double(), wd[i].double(), None, 2, 0) * sd[i].double().view(1, -1, 1, 1)
+                                  + bd[i].double().view(1, -1, 1, 1)) for i in range(G)])             # [G,B,Cout,H,W]
+    assert exp.shape[-2:] == (H, W)
+    wf = torch.cat([(w2 * s2.view(G, Cout, 1, 1, 1)).permute(0, 1, 3, 4, 2).reshape(G, Cout, 9 * Cc),
+                    (wd * sd.view(G, Cout, 1, 1, 1)).reshape(G, Cout, Cx)], dim=2).contiguous()
+    scale = 256.0
+    wf16 = ops.split16(wf.to(d), scale)
+    got = ops.conv2d_with_second_source(y1.permute(0, 1, 3, 4, 2).contiguous().to(d), x.permute(0, 1, 3, 4, 2).contiguous().to(d),
+                                        wf16, scale, (b2 + bd).to(d), splitk=splitk)
+    assert rel_err(got.permute(0, 1, 4, 2, 3), exp) < 3e-6

@@ -16,10 +16,11 @@ def short_name(n):
     n = n.replace("(anonymous namespace)::", "")
     n = re.sub(r"\(.*\)$", "", n).strip()
     n = n.replace(" ", "")
-    m = re.match(r"gemm_f32_kernel<(\d+),(\d+),(\d+),(\d+),(\d+),(\d+),(\d+),(\d+)(?:,\d+)?>", n)
+    m = re.match(r"gemm_f32_kernel<(\d+),(\d+),(\d+),(\d+),(\d+),(\d+),(\d+),(\d+)((?:,\d+)*)>", n)
     if m:       # <BM,BN,WM,WN,AMODE,BMODE,PREC,BSPLIT[,UNMASKED]> -> the profiler's name
         g = m.groups()
-        return "gemm_%s_kernel<%s>" % ("f16x3" if g[6] == "1" else "f32", ",".join(g[:6]))
+        xs = ",xs" if g[8].split(",")[2:3] == ["1"] else ""          # trailing <..., UNMASKED, XS>
+        return "gemm_%s_kernel<%s%s>" % ("f16x3" if g[6] == "1" else "f32", ",".join(g[:6]), xs)
     return n
 
 
