@@ -50,6 +50,7 @@ class GemmDesc(C.Structure):
         ("finite_flag", C.c_void_p), ("finite_bit", C.c_uint32),
         ("Ax", C.c_void_p), ("kx_begin", C.c_int32), ("Hx", C.c_int32), ("Wx", C.c_int32), ("Cx", C.c_int32),
         ("stride_x", C.c_int32), ("gAx", C.c_int64),
+        ("A_alt", C.c_void_p), ("alt_ncols", C.c_int32),
     ]
 
 

@@ -524,7 +524,10 @@ int launch_attention(const AttnArgs& a, hipStream_t st, std::string* err) {
     int nsplit = 1;
     if (a.ws) {
         const long blocks = (long)qblocks * a.H * a.B;
-        nsplit = (int)((1024 + blocks - 1) / blocks);
+        // grid target of the key split (tuning aid ACTMI_ATTN_SPLIT_TARGET; 768 residency slots at three workgroups per CU)
+        static const long target = getenv("ACTMI_ATTN_SPLIT_TARGET") ? atol(getenv("ACTMI_ATTN_SPLIT_TARGET")) : 1024;
+        nsplit = (int)((target + blocks - 1) / blocks);
+        if (nsplit < 1) nsplit = 1;
         if (nsplit > 8) nsplit = 8;
         if (nsplit > tiles / 2) nsplit = tiles / 2 > 0 ? tiles / 2 : 1;
         while (nsplit > 1 && (int64_t)nsplit * a.B * a.Nq * ((int64_t)a.H * a.HD + 2 * a.H) > a.ws_floats) --nsplit;

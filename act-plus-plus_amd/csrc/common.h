@@ -121,9 +121,22 @@ int launch_maxpool_bwd_idx(const uint8_t* arg, const float* dy, float* dx, int n
 
 // ---- LayerNorm (layernorm.hip) ----------------------------------------------------------------
 // y = LN(x + res[m % res_mod]) * w + b ; optional second LN (w2,b2) applied on top.
+// optional extra outputs computed from the finished row while it is still in registers
+struct LnExtra {
+    float* y2 = nullptr;             // y2[row] = y[row] + add2[row % add2_mod]  (add2_mod = 0: add2[row])
+    const float* add2 = nullptr;
+    int add2_mod = 0;
+    float* head_out = nullptr;       // head_out[row][n] = y[row] . head_w[n] + head_b[n], n < head_n  (fp32 FMA)
+    const float* head_w = nullptr;   // [head_n][D]
+    const float* head_b = nullptr;   // [head_n] or NULL
+    int head_n = 0;
+    uint32_t* flag = nullptr;        // OR flag_bit into *flag when a head output is NaN / infinite
+    uint32_t flag_bit = 0;
+};
 int launch_layernorm(const float* x, const float* res, int res_mod, const float* w, const float* b,
                      const float* w2, const float* b2, float* y, int M, int D, float eps, hipStream_t st,
-                     std::string* err, int nsplit = 1, int64_t split_stride = 0, const float* bias = nullptr);
+                     std::string* err, int nsplit = 1, int64_t split_stride = 0, const float* bias = nullptr,
+                     const LnExtra* extra = nullptr);
 
 // ---- attention (attn.hip) -----------------------------------------------------------------------
 typedef actmi_attn_desc AttnArgs;

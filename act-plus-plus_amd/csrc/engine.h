@@ -154,6 +154,8 @@ struct actmi_ctx {
     // activations
     float *act1 = nullptr, *buf[3] = {nullptr, nullptr, nullptr};
     float *X = nullptr, *X1 = nullptr, *Y = nullptr, *ATT = nullptr, *QKV = nullptr, *Hb = nullptr;
+    float* XP = nullptr;               // x + pos of the encoder stream, written by the LayerNorm that produces x (ACTMI_LN_XP=0: off)
+    bool ln_xp = true, ln_head = true; // LayerNorm extras: x + pos second output, action head in the decoder's last LayerNorm
     float *dO = nullptr, *dY = nullptr, *dT2 = nullptr, *dH = nullptr, *hs = nullptr;
     float* attn_ws = nullptr;          // split-KV partials (attn.hip)
     int64_t attn_ws_floats = 0;
@@ -173,6 +175,7 @@ struct LnFuse {
     float* out;
     float eps;
     bool done;
+    const LnExtra* extra = nullptr;    // extra outputs of that LayerNorm (x + pos for the next attention block, the action head)
 };
 int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half = -1, LnFuse* ln = nullptr);
 int engine_destroy(actmi_ctx* ctx);

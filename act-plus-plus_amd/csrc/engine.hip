@@ -214,7 +214,7 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half, LnFuse* ln
             if (ln && groups == 1 && !a.scale && !a.relu && (!a.res || a.ldres == a.N)) {
                 // the LayerNorm that follows reads the slices itself: sum in slice order + bias + residual, as the combine does
                 rc = launch_layernorm(ws, a.res, 0, ln->w, ln->b, ln->w2, ln->b2, ln->out, a.M, a.N, ln->eps, st, &ctx->err, S, slice,
-                                      a.bias);
+                                      a.bias, ln->extra);
                 ln->done = rc == 0;
                 return rc;
             }
@@ -517,6 +517,9 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
     const int64_t BN_ = (int64_t)B * N;
     if ((rc = dev_alloc(ctx, &ctx->X, BN_ * D))) return fail(rc);
     if ((rc = dev_alloc(ctx, &ctx->X1, BN_ * D))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->XP, BN_ * D))) return fail(rc);
+    { const char* e1 = getenv("ACTMI_LN_XP"); ctx->ln_xp = !(e1 && e1[0] == '0'); }
+    { const char* e1 = getenv("ACTMI_LN_HEAD"); ctx->ln_head = !(e1 && e1[0] == '0'); }
     if ((rc = dev_alloc(ctx, &ctx->Y, BN_ * D))) return fail(rc);
     if ((rc = dev_alloc(ctx, &ctx->ATT, BN_ * D))) return fail(rc);
     if ((rc = dev_alloc(ctx, &ctx->QKV, BN_ * 3 * D))) return fail(rc);
@@ -961,7 +964,7 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
 // The transformer's activation buffers as seen by one branch: the samples [b0, b0 + nb) of the batch (token-major [B][N][D]
 // layouts: a batch range is a pointer offset).  half >= 0: one of two concurrent branches (own half of the slice workspace).
 struct TView {
-    float *X, *QKV, *ATT, *Y, *X1, *Hb, *dO, *dY, *dT2, *dH, *hs, *attn_ws;
+    float *X, *XP, *QKV, *ATT, *Y, *X1, *Hb, *dO, *dY, *dT2, *dH, *hs, *attn_ws;
     int64_t attn_ws_floats;
     int half;
 };
@@ -970,7 +973,7 @@ static TView make_view(const actmi_ctx* ctx, int b0, int nb, int half) {
     const int64_t D = g.hidden_dim, F = g.dim_feedforward, Q = g.num_queries, N = ctx->N;
     const int64_t ws_per = ctx->attn_ws_floats / g.max_batch;
     TView v;
-    v.X = ctx->X + b0 * N * D; v.QKV = ctx->QKV + b0 * N * 3 * D; v.ATT = ctx->ATT + b0 * N * D; v.Y = ctx->Y + b0 * N * D;
+    v.X = ctx->X + b0 * N * D; v.XP = ctx->XP + b0 * N * D; v.QKV = ctx->QKV + b0 * N * 3 * D; v.ATT = ctx->ATT + b0 * N * D; v.Y = ctx->Y + b0 * N * D;
     v.X1 = ctx->X1 + b0 * N * D; v.Hb = ctx->Hb + b0 * N * F;
     v.dO = ctx->dO + b0 * Q * D; v.dY = ctx->dY + b0 * Q * D; v.dT2 = ctx->dT2 + b0 * Q * D; v.dH = ctx->dH + b0 * Q * F;
     v.hs = ctx->hs + b0 * Q * D;
@@ -980,13 +983,16 @@ static TView make_view(const actmi_ctx* ctx, int b0, int nb, int half) {
 }
 
 // one post-norm encoder layer on x [B*n][D] in place (transformer.py:211-224)
+// xp_in: V.XP already holds x + pos (written by the LayerNorm that produced x); xp_out: this layer's last LayerNorm writes
+// x + pos of ITS output into V.XP for the next attention block
 int engine_encoder_layer(actmi_ctx* ctx, const EncW& w, const TView& V, const float* pos, int B, int n, const uint8_t* kpm,
-                         hipStream_t st) {
+                         hipStream_t st, bool xp_in, bool xp_out) {
     float* x = V.X;
     const actmi_config& g = ctx->cfg;
     const int D = g.hidden_dim, F = g.dim_feedforward, M = B * n, hd = D / g.nheads;
     GemmArgs qkv = linear_args(x, D, M, D, w.attn.in_w, 3 * D, w.attn.in_b, V.QKV, 3 * D);
-    qkv.A_add = pos; qkv.ld_add = D; qkv.add_mod = n; qkv.add_ncols = 2 * D;     // q = k = x + pos, v = x
+    if (xp_in) { qkv.A_alt = V.XP; qkv.alt_ncols = 2 * D; }                      // q = k = x + pos (a matrix already), v = x
+    else { qkv.A_add = pos; qkv.ld_add = D; qkv.add_mod = n; qkv.add_ncols = 2 * D; }     // q = k = x + pos, v = x
     CHK(ctx_gemm(ctx, qkv, st, V.half));
     AttnArgs at;
     memset(&at, 0, sizeof(at));
@@ -1009,20 +1015,25 @@ int engine_encoder_layer(actmi_ctx* ctx, const EncW& w, const TView& V, const fl
     CHK(ctx_gemm(ctx, f1, st, V.half));
     GemmArgs f2 = linear_args(V.Hb, F, M, F, w.l2w, D, w.l2b, V.Y, D);
     f2.res = V.X1; f2.ldres = D;
-    LnFuse ln2{w.n2w, w.n2b, nullptr, nullptr, x, 1e-5f, false};
+    LnExtra ex;
+    if (xp_out) { ex.y2 = V.XP; ex.add2 = pos; ex.add2_mod = n; }
+    LnFuse ln2{w.n2w, w.n2b, nullptr, nullptr, x, 1e-5f, false, xp_out ? &ex : nullptr};
     CHK(ctx_gemm(ctx, f2, st, V.half, &ln2));
-    if (!ln2.done) CHK(launch_layernorm(V.Y, nullptr, 0, w.n2w, w.n2b, nullptr, nullptr, x, M, D, 1e-5f, st, &ctx->err));
+    if (!ln2.done)
+        CHK(launch_layernorm(V.Y, nullptr, 0, w.n2w, w.n2b, nullptr, nullptr, x, M, D, 1e-5f, st, &ctx->err, 1, 0, nullptr,
+                             xp_out ? &ex : nullptr));
     return 0;
 }
 
 // decoder layer 0 with the constant query path + heads (transformer.py:274-295,175; detr_vae.py:245,252)
-int engine_decoder_infer(actmi_ctx* ctx, const TView& V, int B, float* a_hat, hipStream_t st) {
+int engine_decoder_infer(actmi_ctx* ctx, const TView& V, int B, float* a_hat, hipStream_t st, bool xp_in) {
     const actmi_config& g = ctx->cfg;
     const int D = g.hidden_dim, F = g.dim_feedforward, Q = g.num_queries, N = ctx->N, hd = D / g.nheads;
     const DecW& d = ctx->dec[0];
     float* KV = V.QKV;   // [B*N][2D]
     GemmArgs kv = linear_args(V.X, D, B * N, D, d.cross.in_w + (int64_t)D * D, 2 * D, d.cross.in_b + D, KV, 2 * D);
-    kv.A_add = ctx->pos_tokens; kv.ld_add = D; kv.add_mod = N; kv.add_ncols = D;      // k = memory + pos, v = memory
+    if (xp_in) { kv.A_alt = V.XP; kv.alt_ncols = D; }                                   // k = memory + pos (a matrix already), v = memory
+    else { kv.A_add = ctx->pos_tokens; kv.ld_add = D; kv.add_mod = N; kv.add_ncols = D; }      // k = memory + pos, v = memory
     CHK(ctx_gemm(ctx, kv, st, V.half));
     AttnArgs at;
     memset(&at, 0, sizeof(at));
@@ -1044,17 +1055,28 @@ int engine_decoder_infer(actmi_ctx* ctx, const TView& V, int B, float* a_hat, hi
     CHK(ctx_gemm(ctx, f1, st, V.half));
     GemmArgs f2 = linear_args(V.dH, F, M, F, d.l2w, D, d.l2b, V.dY, D);
     f2.res = V.dT2; f2.ldres = D;
-    LnFuse ln3{d.n3w, d.n3b, ctx->P("transformer.decoder.norm.weight"), ctx->P("transformer.decoder.norm.bias"), V.hs, 1e-5f, false};
+    // norm3 + decoder.norm; the action head (detr_vae.py:252) is computed from the finished row in the same kernel, with the
+    // default-on output guard: an operand that left the fp16 range of the f16x3 products surfaces as inf / NaN in a_hat and
+    // raises the flag (read at the caller's next natural synchronisation: actmi_get_flags)
+    LnExtra hx;
+    const bool head_in_ln = ctx->ln_head && g.action_dim <= 64;
+    if (head_in_ln) {
+        hx.head_out = a_hat; hx.head_w = ctx->P("action_head.weight"); hx.head_b = ctx->P("action_head.bias"); hx.head_n = g.action_dim;
+        hx.flag = ctx->flags; hx.flag_bit = ACTMI_FLAG_OUTPUT;
+    }
+    LnFuse ln3{d.n3w, d.n3b, ctx->P("transformer.decoder.norm.weight"), ctx->P("transformer.decoder.norm.bias"), V.hs, 1e-5f, false,
+               head_in_ln ? &hx : nullptr};
     CHK(ctx_gemm(ctx, f2, st, V.half, &ln3));
     if (!ln3.done)
         CHK(launch_layernorm(V.dY, nullptr, 0, d.n3w, d.n3b, ctx->P("transformer.decoder.norm.weight"),
-                             ctx->P("transformer.decoder.norm.bias"), V.hs, M, D, 1e-5f, st, &ctx->err));
-    GemmArgs ah = linear_args(V.hs, D, M, D, ctx->P("action_head.weight"), g.action_dim, ctx->P("action_head.bias"),
-                              a_hat, g.action_dim);
-    // default-on output guard: an operand that left the fp16 range of the f16x3 products surfaces as inf / NaN in a_hat;
-    // the action head's epilogue raises the flag (read at the caller's next natural synchronisation: actmi_get_flags)
-    ah.finite_flag = ctx->flags; ah.finite_bit = ACTMI_FLAG_OUTPUT;
-    CHK(ctx_gemm(ctx, ah, st, V.half));
+                             ctx->P("transformer.decoder.norm.bias"), V.hs, M, D, 1e-5f, st, &ctx->err, 1, 0, nullptr,
+                             head_in_ln ? &hx : nullptr));
+    if (!head_in_ln) {
+        GemmArgs ah = linear_args(V.hs, D, M, D, ctx->P("action_head.weight"), g.action_dim, ctx->P("action_head.bias"),
+                                  a_hat, g.action_dim);
+        ah.finite_flag = ctx->flags; ah.finite_bit = ACTMI_FLAG_OUTPUT;
+        CHK(ctx_gemm(ctx, ah, st, V.half));
+    }
     if (V.half <= 0) ctx->dbg["hs"] = {ctx->hs, (int64_t)ctx->last_B * Q * D};
     return 0;
 }
@@ -1091,9 +1113,13 @@ int engine_forward_infer(actmi_ctx* ctx, const float* qpos, const void* image, i
     ctx->last_B = B;
     auto run_transformer = [&](int b0, int nb, hipStream_t ts, int half) -> int {
         const TView V = make_view(ctx, b0, nb, half);
+        // x + pos as a matrix of its own (written by each layer's last LayerNorm) wherever the consumer's column split falls on
+        // a tile boundary: the packed QKV products of layers 1.. and the decoder's KV product are then plain GEMMs
+        const bool xp_qkv = ctx->ln_xp && ((2 * D) % 128) == 0, xp_kv = ctx->ln_xp && (D % 128) == 0;
         for (int l = 0; l < g.enc_layers; ++l)
-            CHK(engine_encoder_layer(ctx, ctx->enc[l], V, ctx->pos_tokens, nb, N, nullptr, ts));
-        return engine_decoder_infer(ctx, V, nb, a_hat + (int64_t)b0 * g.num_queries * g.action_dim, ts);
+            CHK(engine_encoder_layer(ctx, ctx->enc[l], V, ctx->pos_tokens, nb, N, nullptr, ts, l > 0 && xp_qkv,
+                                     l + 1 < g.enc_layers ? xp_qkv : xp_kv));
+        return engine_decoder_infer(ctx, V, nb, a_hat + (int64_t)b0 * g.num_queries * g.action_dim, ts, xp_kv);
     };
     // encoder + decoder as two concurrent branches over the two halves of the batch (samples are independent): the 304-workgroup
     // launches (out-proj, FFN2: 59 % of the 512 residency slots) of one half run beside the other half's launches

@@ -130,7 +130,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
     } else {
         offA = (int64_t)g * p.gA; offB = (int64_t)g * p.gB; offC = (int64_t)g * p.gC; offRes = (int64_t)g * p.gRes;
     }
-    const float* __restrict__ A = p.A + offA;
+    // A_alt (row-major forms): the column blocks n0 < alt_ncols read their rows from a second matrix of the same shape (the
+    // packed QKV product: q and k project x + pos, v projects x -- transformer.py:216-217 -- with x + pos written by the
+    // LayerNorm that produced x); block-uniform, costs nothing in the loop
+    const float* __restrict__ A = ((AMODE == A_N) && p.A_alt != nullptr && n0 < p.alt_ncols ? p.A_alt : p.A) + offA;
     const float* __restrict__ Bw = p.Bw + offB;
 
     uint64_t* stamp = p.stamps ? p.stamps + ((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 4 : nullptr;
@@ -1061,6 +1064,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t st, std::string* err) {
             // zero-filled beyond K, so the pad never contributes)
             if ((a.K & 3) && a.lda < ((a.K + 3) & ~3)) return fail("K % 4 != 0 needs rows padded to a multiple of 4");
             if (a.A_add && ((a.ld_add & 3) || a.add_mod <= 0 || ((uintptr_t)a.A_add & 15))) return fail("bad addend");
+            if (a.A_alt && (a.A_add || a.a_rowmap || (a.alt_ncols % 128) || ((uintptr_t)a.A_alt & 15))) return fail("A_alt: no addend / row gather, alt_ncols a multiple of 128");
             amode = A_N;
         } else if (a.mode == 1) {
             if (a.K & 3) return fail("K must be a multiple of 4");

@@ -221,17 +221,23 @@ class InferRig:
         self.image = self.image_host.to(dev)                    # resident in HBM before any timed region
         self.a_hat = torch.empty((B, cfg.num_queries, cfg.action_dim), dtype=torch.float32, device=dev)
         self.ens = ops.TemporalEnsemble(B, cfg.num_queries, cfg.action_dim, 0.01, dev)
-        self.replay = None
+        self.replay, self.pipe = None, None
         if graph:
             try:
-                self.replay = self.eng.capture_infer(B, with_ensemble=self.ens)     # forward + ensemble: ONE graph launch
+                # forward + ensemble as ONE graph launch; two graphs over two input buffers (engine.InferPipeline) so that the
+                # with_h2d leg can copy the next step's frames while this step runs.  The headline leg replays buffer 0 only.
+                from actmi.engine import InferPipeline
+                self.pipe = InferPipeline(self.eng, B, with_ensemble=self.ens)
+                self.replay = self.pipe.slots[0]
             except Exception as e:                               # capture unsupported -> eager launches
                 log(f"hipGraph capture failed ({e}); falling back to eager launches")
+                self.replay, self.pipe = None, None
         if self.replay is not None:
-            # the graph's static input buffers ARE the resident inputs (a deployment writes its frames there: the H2D copy of
-            # the with_h2d leg lands in them directly), so a step is the graph launch alone
+            # the graph's static input buffers ARE the resident inputs (a deployment writes its frames there), so a step is the
+            # graph launch alone
             s_qpos, s_img, _ = self.replay.static
             s_qpos.copy_(self.qpos); s_img.copy_(self.image)
+            self.qpos_host = self.qpos.cpu().pin_memory()
             self.qpos, self.image = s_qpos, s_img
             torch.cuda.synchronize(dev)
 
@@ -256,12 +262,23 @@ class InferRig:
         return self.replay.static[2] if self.replay is not None else self.a_hat
 
     def timed(self, steps, warmup, barrier=None, with_h2d=False):
-        """seconds for exactly `steps` steps, bracketed by barrier + synchronize on both sides."""
+        """seconds for exactly `steps` steps, bracketed by barrier + synchronize on both sides.  with_h2d: every step's frames
+        come from pinned host memory -- double-buffered when the step is graphed (the copy of step t + 1 runs beside step t)."""
         torch = self.torch
         sync = barrier or (lambda: torch.cuda.synchronize(self.dev))
         for _ in range(warmup):
             self.step()
         sync()
+        if with_h2d and self.pipe is not None:
+            pipe = self.pipe
+            t0 = time.perf_counter()
+            pipe.feed(self.qpos_host, self.image_host)
+            for i in range(steps):
+                if i + 1 < steps:
+                    pipe.feed(self.qpos_host, self.image_host)
+                pipe.step()
+            sync()
+            return time.perf_counter() - t0
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step(self.image_host if with_h2d else None)
@@ -269,7 +286,7 @@ class InferRig:
         return time.perf_counter() - t0
 
     def close(self):
-        self.replay = None
+        self.replay = self.pipe = None
         self.eng = None
         self.torch.cuda.empty_cache()
 
@@ -454,7 +471,9 @@ def bench_infer(args, cfg, B, ctx):
         "sustained": sustained,
         "with_h2d": {"ms_per_step": h2d_dt / args.steps * 1e3, "value": B * args.steps / h2d_dt, "unit": "policy steps/s",
                      "h2d_bytes_per_step": int(rig.image_host.numel()),
-                     "note": "fresh u8 frames copied from pinned host memory every step (rank 0 only); not the headline"},
+                     "note": "fresh u8 frames (and qpos) copied from pinned host memory every step, double-buffered: the copy "
+                             "of step t+1 runs on a copy stream beside the graph of step t (engine.InferPipeline); rank 0 only; "
+                             "not the headline"},
         "kernels": kernels,
         "step_latency_ms": lat,
         "ranks_seen": ranks_seen,

@@ -169,6 +169,11 @@ typedef struct actmi_gemm_desc {
     const float* Ax;
     int32_t kx_begin, Hx, Wx, Cx, stride_x;
     int64_t gAx;
+    /* mode 0, ta 0, optional: the output columns n < alt_ncols (a multiple of 128) contract the rows of A_alt (same shape / lda /
+     * group stride as A) instead of A -- nn.MultiheadAttention's packed projection with q = k = x + pos, v = x
+     * (transformer.py:216-217) when x + pos already exists as a matrix */
+    const float* A_alt;
+    int32_t alt_ncols;
 } actmi_gemm_desc;
 
 /* GEMM / implicit-GEMM convolution on PRE-SPLIT operands (the inference path's form of actmi_gemm_desc with prec f16x3;
