@@ -22,7 +22,7 @@ _CHECK_FINITE = os.environ.get("ACTMI_CHECK_FINITE") == "1"
 
 class ACTEngine:
     def __init__(self, cfg: ACTConfig, max_batch: int = 8, device: str = "cuda:0", training: bool = False,
-                 gemm_prec: str = None):
+                 gemm_prec: str = None, train_prec: str = None):
         """gemm_prec: "f16x3" (default; fp32 products formed from three fp16 MFMA products of exactly split operands,
         fp32-grade results) or "f32" (native fp32 MFMA); None = environment ACTMI_GEMM_PREC or the default."""
         if not torch.cuda.is_available():
@@ -52,6 +52,10 @@ class ACTEngine:
         self.h = h
         if gemm_prec is not None:
             L.check(self.lib.actmi_set_gemm_prec(self.h, {"f32": 1, "f16x3": 2}[gemm_prec]), self.h, "set_gemm_prec")
+        if train_prec is not None:
+            # "bf16": the GEMMs of the training step form ONE bf16 product per fp32 product (fp32 accumulate, fp32 master weights
+            # and optimizer state) -- BASELINE config 3's bf16, an opt-in speed mode (~1e-2 relative); None / "f16x3" = default
+            L.check(self.lib.actmi_set_train_prec(self.h, {"f32": 1, "f16x3": 2, "bf16": 3}[train_prec]), self.h, "set_train_prec")
         self.spec = act_state_dict_spec(cfg)
         self._finalized = False
         # attributes imitate_episodes.py touches on policy.model

@@ -151,6 +151,7 @@ def load():
         "actmi_debug_tensor": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i64)], i32),
         "actmi_debug_stop_after": ([vp, C.c_char_p], i32),
         "actmi_set_gemm_prec": ([vp, i32], i32),
+        "actmi_set_train_prec": ([vp, i32], i32),
         "actmi_get_flags": ([vp, C.POINTER(C.c_uint32), i32, vp], i32),
         "actmi_flags_ptr": ([vp, C.POINTER(vp)], i32),
         "actmi_profile_enable": ([i32], i32),

@@ -368,6 +368,15 @@ int actmi_set_gemm_prec(actmi_handle h, int prec) {
     return 0;
 }
 
+int actmi_set_train_prec(actmi_handle h, int prec) {
+    if (!h) return ACTMI_E_INVALID;
+    ENTER(h);
+    if (prec != 0 && prec != ACTMI_PREC_BF16 && prec != ACTMI_PREC_F16X3 && prec != ACTMI_PREC_F32) { h->err = "train prec must be 0 or ACTMI_PREC_*"; return ACTMI_E_INVALID; }
+    h->train_prec = (prec == h->gemm_prec) ? 0 : prec;
+    if (h->train_prec != 0 && h->train_prec != ACTMI_PREC_BF16) { h->err = "only ACTMI_PREC_BF16 differs from the handle precision"; h->train_prec = 0; return ACTMI_E_INVALID; }
+    return 0;
+}
+
 int actmi_get_flags(actmi_handle h, uint32_t* host_flags, int clear, void* stream) {
     if (!h || !host_flags) return ACTMI_E_INVALID;
     ENTER(h);

@@ -104,6 +104,9 @@ struct actmi_ctx {
     float* pbase = nullptr;
     float* p16base = nullptr;          // fp16-split image of the parameter arena (B operands of the f16x3 GEMM)
     int gemm_prec = 0;                 // ACTMI_PREC_* used by the forward GEMMs of this handle
+    int train_prec = 0;                // ACTMI_PREC_BF16: the GEMMs of the TRAINING step form one bf16 product per fp32 product
+                                       // (opt-in speed mode, actmi_set_train_prec / ACTMI_TRAIN_PREC=bf16); 0 = gemm_prec
+    int prec_override = 0;             // set for the duration of train_forward / train_backward (PrecScope)
     // range guard of the f16x3 forward: one power-of-two scale per parameter for its split image, chosen at
     // finalize so that max|w| * scale lands in [2^13, 2^14) (capped at 2^12); device copies for the split kernel
     std::vector<float> pscale;         // per parameter (index = position in params)
@@ -178,6 +181,12 @@ struct LnFuse {
     const LnExtra* extra = nullptr;    // extra outputs of that LayerNorm (x + pos for the next attention block, the action head)
 };
 int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half = -1, LnFuse* ln = nullptr);
+// precision of the GEMMs issued while a training call is running (restored on every exit path)
+struct PrecScope {
+    actmi_ctx* c;
+    explicit PrecScope(actmi_ctx* ctx) : c(ctx) { c->prec_override = c->train_prec; }
+    ~PrecScope() { c->prec_override = 0; }
+};
 int engine_destroy(actmi_ctx* ctx);
 const char* engine_create_error();
 int engine_finalize(actmi_ctx* ctx, hipStream_t st);

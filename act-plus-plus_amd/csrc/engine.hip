@@ -155,12 +155,12 @@ int dev_alloc(actmi_ctx* ctx, float** p, int64_t nfloats) {
 
 int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half, LnFuse* ln) {
     if (ln) ln->done = false;
-    a.prec = ctx->gemm_prec;
+    a.prec = ctx->prec_override ? ctx->prec_override : ctx->gemm_prec;
     // ws_half 0 / 1: this launch belongs to one of two concurrent branches, each with its own half of the slice workspace
     const int64_t ws_part = (ctx->splitk_ws_floats / ctx->nbranch) & ~(int64_t)3;
     float* const ws = ctx->splitk_ws ? ctx->splitk_ws + (ws_half > 0 ? ws_half * ws_part : 0) : nullptr;
     const int64_t ws_floats = ws_half >= 0 ? ws_part : ctx->splitk_ws_floats;
-    if (ctx->gemm_prec == ACTMI_PREC_F16X3 && a.tb == 0) {
+    if (a.prec == ACTMI_PREC_F16X3 && a.tb == 0) {
         // B is a weight matrix: use its pre-split image (same offsets) where one exists
         if (a.Bw >= ctx->pbase && a.Bw < ctx->pbase + ctx->ptotal) {
             a.b_scale = engine_weight_scale(ctx, a.Bw);
@@ -403,6 +403,7 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
         // forward precision of this handle: fp16-split products unless ACTMI_GEMM_PREC=f32 asks for the native fp32 MFMA
         const char* e = getenv("ACTMI_GEMM_PREC");
         ctx->gemm_prec = (e && e[0] == 'f' && e[1] == '3') ? ACTMI_PREC_F32 : ACTMI_PREC_F16X3;
+        { const char* tp = getenv("ACTMI_TRAIN_PREC"); if (tp && tp[0] == 'b') ctx->train_prec = ACTMI_PREC_BF16; }
         if (ctx->ptotal & 3) { ctx->err = "parameter arena not a multiple of 4 floats"; return fail(ACTMI_E_LAUNCH); }
         if ((rc = dev_alloc(ctx, &ctx->p16base, ctx->ptotal))) return fail(rc);
         { const char* vp = getenv("ACTMI_CONV1_VPOOL"); ctx->conv1_vpool = !(vp && vp[0] == '0'); }

@@ -40,7 +40,11 @@ enum { B_N = 0, B_T = 1, B_WGRAD = 2 };
 //              2^-22 relative -- below the fp32 accumulation noise of a K >= 64 dot product -- so results are fp32-grade
 //              (measured: same |a_hat - reference| as PREC_F32), while the fp16 pipe is 16x wider: 3 products still
 //              leave 5.3x the native fp32 MFMA rate.  Operands must be finite and |x| < 65504.
-enum { PREC_F32 = 0, PREC_F16X3 = 1 };
+//   PREC_BF16  ONE bf16 product per fp32 product on v_mfma_f32_32x32x16_bf16 (operands rounded to 8 significand bits, fp32
+//              accumulation): the opt-in "speed mode" of the TRAINING step (BASELINE config 3 names bf16; fp32 master weights and
+//              optimizer state).  A third of the MFMAs and half the LDS traffic of PREC_F16X3, results at ~1e-2 relative: never the
+//              default, never the inference path (the 1e-4 parity bar rules it out -- DESIGN.md section 4).
+enum { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16 = 2 };
 constexpr int ACTMI_PREC_DEFAULT_IS = ACTMI_PREC_F32;      // library default when neither descriptor nor environment says
 
 #ifndef ACTMI_LDS_PAD
@@ -53,6 +57,14 @@ constexpr int stage_f4() { return NPL * ((BM + LDS_PAD) + (BN + LDS_PAD)); }
 
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// 4 floats -> 4 bf16 (round to nearest even; v_cvt_pk_bf16_f32 keeps a NaN a NaN), packed in 8 bytes
+__device__ __forceinline__ uint2 pack_bf16x4(const f32x4 v) {
+    const bf16x2 a = {(__bf16)v[0], (__bf16)v[1]}, b = {(__bf16)v[2], (__bf16)v[3]};
+    return uint2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+}
 
 // Row swizzle of the transposed-staging forms.  A thread of those loaders holds 4 CONSECUTIVE out-rows of one k group, so
 // the 8/16 lanes of an LDS store group would hit rows 64 bytes apart -- 2 distinct bank slots, a 4- to 8-way conflict.
@@ -456,10 +468,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                 for (int i = 0; i < 4; ++i) {
                     const f32x4 v = f32x4{R.ra[0][i], R.ra[1][i], R.ra[2][i], R.ra[3][i]} * pre_a;
                     uint2 hi, lo;
-                    split16(v, hi, lo);
                     const int row = swz_row(a_og * 4 + i);
+                    if (PREC == PREC_BF16) sa8[(((a_kg >> 1) * 2 + 0) * PSA + row) * 2 + (a_kg & 1)] = pack_bf16x4(v);
+                    else {
+                    split16(v, hi, lo);
                     sa8[(((a_kg >> 1) * 2 + 0) * PSA + row) * 2 + (a_kg & 1)] = hi;
                     sa8[(((a_kg >> 1) * 2 + 1) * PSA + row) * 2 + (a_kg & 1)] = lo;
+                    }
                 }
             }
         } else {
@@ -470,10 +485,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                 if (AMODE == A_CONV || AMODE == A_DGRAD || MASKED) v = R.ra_ok[i] ? v : zero4;
                 if (MASKED) v *= pre_a;
                 uint2 hi, lo;
-                split16(v, hi, lo);
                 const int row = srow + RPP * i;
+                if (PREC == PREC_BF16) sa8[(((cidx >> 1) * 2 + 0) * PSA + row) * 2 + (cidx & 1)] = pack_bf16x4(v);
+                else {
+                split16(v, hi, lo);
                 sa8[(((cidx >> 1) * 2 + 0) * PSA + row) * 2 + (cidx & 1)] = hi;
                 sa8[(((cidx >> 1) * 2 + 1) * PSA + row) * 2 + (cidx & 1)] = lo;
+                }
             }
         }
         if (BMODE == B_N) {
@@ -482,12 +500,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                 f32x4 v = (!MASKED || R.rb_ok[i]) ? R.rb[i] : zero4;
                 if (MASKED && !BSPLIT) v *= pre_b;
                 uint2 hi, lo;
+                const int row = srow + RPP * i;
+                if (PREC == PREC_BF16) { sb8[(((cidx >> 1) * 2 + 0) * PSB + row) * 2 + (cidx & 1)] = pack_bf16x4(v); continue; }
                 if (BSPLIT) {     // weights split ahead of time: each 16-byte group is {4 hi halfs, 4 lo halfs}
                     const uint4 u = __builtin_bit_cast(uint4, v);
                     hi = uint2{u.x, u.y};
                     lo = uint2{u.z, u.w};
                 } else split16(v, hi, lo);
-                const int row = srow + RPP * i;
                 sb8[(((cidx >> 1) * 2 + 0) * PSB + row) * 2 + (cidx & 1)] = hi;
                 sb8[(((cidx >> 1) * 2 + 1) * PSB + row) * 2 + (cidx & 1)] = lo;
             }
@@ -497,10 +516,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                 for (int i = 0; i < 4; ++i) {
                     const f32x4 v = f32x4{R.rb[0][i], R.rb[1][i], R.rb[2][i], R.rb[3][i]} * pre_b;
                     uint2 hi, lo;
-                    split16(v, hi, lo);
                     const int row = swz_row(b_og * 4 + i);
+                    if (PREC == PREC_BF16) sb8[(((b_kg >> 1) * 2 + 0) * PSB + row) * 2 + (b_kg & 1)] = pack_bf16x4(v);
+                    else {
+                    split16(v, hi, lo);
                     sb8[(((b_kg >> 1) * 2 + 0) * PSB + row) * 2 + (b_kg & 1)] = hi;
                     sb8[(((b_kg >> 1) * 2 + 1) * PSB + row) * 2 + (b_kg & 1)] = lo;
+                    }
                 }
             }
         }
@@ -548,8 +570,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nsteps = kt_end - kt_begin;
-    if constexpr (PREC == PREC_F16X3) {
-        // fp16-split main loop.  A 32-deep K tile is only 24 MFMAs (768 pipe cycles) per wave here -- a fifth of the
+    if constexpr (PREC != PREC_F32) {
+        // fp16-split (or single bf16 product) main loop.  A 32-deep K tile is only 24 MFMAs (768 pipe cycles) per wave here -- a fifth of the
         // fp32 instruction's time -- so global loads run TWO tiles ahead of the MFMAs (two register stages), the LDS
         // stage one tile ahead, and the loop body is kept ONE basic block (tail loads are clamped to the last tile
         // instead of branched around; a surplus stage store is harmless) so that the scheduler can weave the next
@@ -564,13 +586,24 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     ah[s2][i] = sa[(kg * 2 + 0) * PSA + arow[i]];
-                    al[s2][i] = sa[(kg * 2 + 1) * PSA + arow[i]];
+                    if (PREC == PREC_F16X3) al[s2][i] = sa[(kg * 2 + 1) * PSA + arow[i]];
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     bh[s2][j] = sb[(kg * 2 + 0) * PSB + bcol[j]];
-                    bl[s2][j] = sb[(kg * 2 + 1) * PSB + bcol[j]];
+                    if (PREC == PREC_F16X3) bl[s2][j] = sb[(kg * 2 + 1) * PSB + bcol[j]];
                 }
+            }
+            if constexpr (PREC == PREC_BF16) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[s2][i]),
+                                                                                __builtin_bit_cast(bf16x8, bh[s2][j]), acc[i][j], 0, 0, 0);
+                return;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
@@ -713,7 +746,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
     float* C2 = p.C2 ? p.C2 + (int64_t)g * p.gC2out : nullptr;
     // a pre-split B image may carry a power-of-two scale (keeps small weights' lo pieces out of fp16 subnormals)
     float alpha = p.alpha != 0.f ? p.alpha : 1.f;
-    if (PREC == PREC_F16X3) {
+    if (PREC != PREC_F32) {
         if (p.b_scale != 0.f) alpha /= p.b_scale;
         if (p.a_scale != 0.f) alpha /= p.a_scale;
         if (p.a_scale_dev) alpha /= *p.a_scale_dev;
@@ -941,10 +974,10 @@ int launch_cfg_u(const GemmArgs& a, hipStream_t st) {
         // ACTMI_PROF_SHAPES=1: one profile class per distinct launch shape (bench.py --shapes: the per-shape table)
         static const bool by_shape = getenv("ACTMI_PROF_SHAPES") && getenv("ACTMI_PROF_SHAPES")[0] == '1';
         if (by_shape)
-            snprintf(nm, sizeof(nm), "gemm_%s_kernel<%d,%d,%d,%d,%d,%d%s>[M=%d,N=%d,K=%d,g=%d,sk=%d,wgs=%d]", PREC ? "f16x3" : "f32",
+            snprintf(nm, sizeof(nm), "gemm_%s_kernel<%d,%d,%d,%d,%d,%d%s>[M=%d,N=%d,K=%d,g=%d,sk=%d,wgs=%d]", PREC == PREC_BF16 ? "bf16" : PREC ? "f16x3" : "f32",
                      BM, BN, WM, WN, AMODE, BMODE, XS ? ",xs" : "", a.M, a.N, a.K, a.groups, splitk, tiles_m * tiles_n * a.groups * splitk);
         else
-            snprintf(nm, sizeof(nm), "gemm_%s_kernel<%d,%d,%d,%d,%d,%d%s>", PREC ? "f16x3" : "f32", BM, BN, WM, WN, AMODE, BMODE, XS ? ",xs" : "");
+            snprintf(nm, sizeof(nm), "gemm_%s_kernel<%d,%d,%d,%d,%d,%d%s>", PREC == PREC_BF16 ? "bf16" : PREC ? "f16x3" : "f32", BM, BN, WM, WN, AMODE, BMODE, XS ? ",xs" : "");
         const double g = a.groups;
         double abytes;
         if (AMODE == A_CONV) abytes = (double)(a.M / (a.Ho * a.Wo)) * a.H * a.W * a.Cin + (XS ? (double)a.M * a.Cx : 0.0);
@@ -961,7 +994,7 @@ int launch_cfg_u(const GemmArgs& a, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int PREC, int BSPLIT>
 int launch_cfg_b(const GemmArgs& a, hipStream_t st) {
-    constexpr bool HOT = PREC == PREC_F16X3 && BMODE == B_N && (AMODE == A_N || AMODE == A_NADD || AMODE == A_CONV);
+    constexpr bool HOT = PREC != PREC_F32 && BMODE == B_N && (AMODE == A_N || AMODE == A_NADD || AMODE == A_CONV);
     if constexpr (HOT) {
         const bool one_a = (a.a_scale == 0.f || a.a_scale == 1.f) && !a.a_scale_dev;
         const bool one_b = BSPLIT || ((a.b_scale == 0.f || a.b_scale == 1.f) && !a.b_scale_dev);
@@ -1035,6 +1068,28 @@ int launch_modes(const GemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
+#ifdef ACTMI_GEMM_TU_BF16
+// second translation unit (gemm_bf16.hip includes this file): the bf16 instantiations only, so that the two halves of the
+// template zoo compile in parallel
+int launch_gemm_bf16(int amode, int bmode, bool has_add, const GemmArgs& a, hipStream_t st) {
+    int rc;
+#define ACTMI_DISPATCH(PREC)                                                                                       \
+    if (amode == A_N && bmode == B_N && has_add) rc = launch_modes<A_NADD, B_N, PREC>(a, st);                      \
+    else if (amode == A_N && bmode == B_N) rc = launch_modes<A_N, B_N, PREC>(a, st);                               \
+    else if (amode == A_CONV && bmode == B_N) rc = launch_modes<A_CONV, B_N, PREC>(a, st);                         \
+    else if (amode == A_DGRAD && bmode == B_N) rc = launch_modes<A_DGRAD, B_N, PREC>(a, st);                       \
+    else if (amode == A_N && bmode == B_T) rc = launch_modes<A_N, B_T, PREC>(a, st);                               \
+    else if (amode == A_T && bmode == B_T) rc = launch_modes<A_T, B_T, PREC>(a, st);                               \
+    else if (amode == A_T && bmode == B_WGRAD) rc = launch_modes<A_T, B_WGRAD, PREC>(a, st);                       \
+    else if (amode == A_T && bmode == B_N) rc = launch_modes<A_T, B_N, PREC>(a, st);                               \
+    else rc = -1002;
+    ACTMI_DISPATCH(PREC_BF16)
+#undef ACTMI_DISPATCH
+    return rc;
+}
+#else
+int launch_gemm_bf16(int amode, int bmode, bool has_add, const GemmArgs& a, hipStream_t st);
+
 int launch_gemm(const GemmArgs& a_in, hipStream_t st, std::string* err) {
     GemmArgs a = a_in;
     if (a.groups <= 0) a.groups = 1;
@@ -1104,7 +1159,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t st, std::string* err) {
         return (e[0] == 'f' && e[1] == '3') ? ACTMI_PREC_F32 : ACTMI_PREC_F16X3;
     }();
     const int prec = a.prec ? a.prec : env_prec;
-    if (prec != ACTMI_PREC_F32 && prec != ACTMI_PREC_F16X3) return fail("bad prec");
+    if (prec != ACTMI_PREC_F32 && prec != ACTMI_PREC_F16X3 && prec != ACTMI_PREC_BF16) return fail("bad prec");
     if (a.b_split && (prec != ACTMI_PREC_F16X3 || bmode != B_N || !(amode == A_N || amode == A_CONV)))
         return fail("b_split needs prec f16x3 and the forward operand forms");
 #define ACTMI_DISPATCH(PREC)                                                                                       \
@@ -1117,9 +1172,14 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t st, std::string* err) {
     else if (amode == A_T && bmode == B_WGRAD) rc = launch_modes<A_T, B_WGRAD, PREC>(a, st);                       \
     else if (amode == A_T && bmode == B_N) rc = launch_modes<A_T, B_N, PREC>(a, st);                               \
     else return fail("operand form combination not instantiated");
-    if (prec == ACTMI_PREC_F16X3) { ACTMI_DISPATCH(PREC_F16X3) } else { ACTMI_DISPATCH(PREC_F32) }
+    if (prec == ACTMI_PREC_BF16) {
+        if (a.Ax) return fail("a second source (Ax) needs prec f16x3");
+        rc = launch_gemm_bf16(amode, bmode, a.A_add != nullptr, a, st);
+        if (rc == -1002) return fail("operand form combination not instantiated");
+    } else if (prec == ACTMI_PREC_F16X3) { ACTMI_DISPATCH(PREC_F16X3) } else { ACTMI_DISPATCH(PREC_F32) }
 #undef ACTMI_DISPATCH
     if (rc == -1001) return fail("a second source (Ax) needs prec f16x3, pre-split weights (b_split), K % 32 == 0 and a plain epilogue");
     if (rc != 0 && err) *err = std::string("gemm launch: ") + hipGetErrorString((hipError_t)rc);
     return rc == 0 ? 0 : -3;
 }
+#endif  // ACTMI_GEMM_TU_BF16

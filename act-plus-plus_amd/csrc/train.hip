@@ -56,7 +56,7 @@ GemmArgs G0() {
 // B is a parameter), the backward forms take the handle precision directly
 int tgemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st) {
     if (a.ta == 0 && a.tb == 0 && a.mode != 2) return ctx_gemm(ctx, a, st);
-    a.prec = ctx->gemm_prec;
+    a.prec = ctx->prec_override ? ctx->prec_override : ctx->gemm_prec;
     TrainState* T = ctx->train;
     if (a.splitk > 1 && a.split_stride == 0 && T && T->det_ws && !a.rowmap && !a.C2 && !a.mask && a.groups_inner == 0) {
         // C += A B with the contraction split over the grid.  The atomic form (every split adds into C) is not run-to-run
@@ -603,6 +603,7 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
     if (!ctx->finalized) { ctx->err = "forward before finalize"; return ACTMI_E_STATE; }
     if (B < 1 || B > ctx->cfg.max_batch) { ctx->err = "batch exceeds max_batch"; return ACTMI_E_INVALID; }
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) { ctx->err = "dropout_p must be in [0, 1)"; return ACTMI_E_INVALID; }
+    PrecScope prec_scope(ctx);               // the opt-in bf16 product mode covers the GEMMs of this call only
     TrainState& T = *ctx->train;
     const actmi_config& g = ctx->cfg;
     const int C = g.num_cams, D = g.hidden_dim, F = g.dim_feedforward, Q = g.num_queries, N = ctx->N, w0 = g.base_width,
@@ -792,6 +793,7 @@ int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt,
 int train_backward(actmi_ctx* ctx, float loss_scale, hipStream_t st) {
     ctx->err.clear();
     if (!ctx->train || !ctx->train->have_forward) { ctx->err = "backward before forward_train"; return ACTMI_E_STATE; }
+    PrecScope prec_scope(ctx);
     TrainState& T = *ctx->train;
     const actmi_config& g = ctx->cfg;
     const int B = T.B, C = g.num_cams, D = g.hidden_dim, F = g.dim_feedforward, Q = g.num_queries, N = ctx->N,

@@ -63,6 +63,7 @@ typedef struct actmi_config {
  * torchvision Conv2d+FrozenBatchNorm2d (backbone.py:47-57). */
 #define ACTMI_PREC_F32 1
 #define ACTMI_PREC_F16X3 2
+#define ACTMI_PREC_BF16 3      /* one bf16 MFMA product per fp32 product, fp32 accumulate: ~1e-2 relative; training speed mode only */
 
 typedef struct actmi_gemm_desc {
     const float* A;
@@ -402,6 +403,12 @@ int actmi_debug_stop_after(actmi_handle h, const char* stage);
 /* precision of the handle's forward GEMMs / convolutions: ACTMI_PREC_F32 or ACTMI_PREC_F16X3 (the default, unless the
  * environment says ACTMI_GEMM_PREC=f32).  Call before actmi_finalize (the split weight image is built there). */
 int actmi_set_gemm_prec(actmi_handle h, int prec);
+/* precision of the GEMMs of the TRAINING step (actmi_forward_train / actmi_backward): 0 = the handle's forward precision (the
+ * default: fp32-grade f16x3 products), ACTMI_PREC_BF16 = one bf16 product per fp32 product with fp32 accumulation, fp32 master
+ * weights and optimizer state -- BASELINE config 3's "bf16" as written, an opt-in speed mode whose losses / gradients agree
+ * with the reference to ~1e-2 relative only (tests/test_gpu_training.py); inference never uses it.  Also ACTMI_TRAIN_PREC=bf16.
+ * The direct kernels of the step (stem, layer1, attention forward) keep their f16x3 arithmetic. */
+int actmi_set_train_prec(actmi_handle h, int prec);
 
 /* ---- range / finiteness guard (default on) --------------------------------------------------------- */
 /* The handle keeps a device flag word raised by its own kernels: ACTMI_FLAG_OUTPUT = an inference output (a_hat) was NaN /
