@@ -21,6 +21,7 @@
 #include "dropout.h"
 #include "split16.h"
 #include <cstdio>
+#include <string>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1053,6 +1054,19 @@ int launch_modes(const GemmArgs& a, hipStream_t st) {
             return factor * ((double)a.M * a.N * nzs) / ((double)rounds * 256 * BM * BN);
         };
         eL = eff(128, 128, 1.00); eM = eff(128, 64, 0.95); eS = eff(64, 64, 0.88);
+    }
+    // tuning aid: per-shape tile overrides "M,N,K=L|M|S;..." (ACTMI_TILE_HINTS), e.g. "4808,512,512=S;9616,512,512=M"
+    static const std::string hints = getenv("ACTMI_TILE_HINTS") ? getenv("ACTMI_TILE_HINTS") : "";
+    if (!hints.empty() && a.tile_hint == 0) {
+        char key[64];
+        snprintf(key, sizeof(key), "%d,%d,%d=", a.M, a.N, a.K);
+        const size_t pos = hints.find(key);
+        if (pos != std::string::npos && (pos == 0 || hints[pos - 1] == ';')) {
+            const char c = hints[pos + strlen(key)];
+            if (c == 'L') return launch_cfg<128, 128, 64, 64, AMODE, BMODE, PREC>(a, st);
+            if (c == 'M') return launch_cfg<128, 64, 64, 32, AMODE, BMODE, PREC>(a, st);
+            if (c == 'S') return launch_cfg<64, 64, 32, 32, AMODE, BMODE, PREC>(a, st);
+        }
     }
     static const char* force = getenv("ACTMI_GEMM_CFG");      // tuning aid: L / M / S
     if (force && force[0] == 'L') return launch_cfg<128, 128, 64, 64, AMODE, BMODE, PREC>(a, st);
