@@ -279,6 +279,17 @@ class DiffusionNet:
         return ops.groupnorm(z, w[p + "blocks.1.block.1.weight"], w[p + "blocks.1.block.1.bias"], 8, act="mish", res=res,
                              res_after=True)
 
+    def _step_embedding(self, timestep, half):
+        """SinusoidalPosEmb of a diffusion step as a device row [1, 2 * half]; cached per step, so a step seen before costs no
+        host-to-device copy (none at all inside a captured graph: capture_infer warms every step of the schedule first)."""
+        cache = self.__dict__.setdefault("_temb", {})
+        key = (timestep, half)
+        if key not in cache:
+            e = np.exp(np.arange(half, dtype=np.float32) * np.float32(-(math.log(10000) / (half - 1))))
+            arg = np.float32(timestep) * e
+            cache[key] = torch.from_numpy(np.concatenate([np.sin(arg), np.cos(arg)]).astype(np.float32)).view(1, -1).to(self.dev)
+        return cache[key]
+
     @_on_own_device
     def unet(self, sample, timestep, cond):
         """ConditionalUnet1D.forward on channel-last sequences: sample [B][T][A] -> noise prediction [B][T][A]."""
@@ -286,9 +297,7 @@ class DiffusionNet:
         B = sample.shape[0]
         dsed = w["diffusion_step_encoder.3.weight"].shape[0]
         half = dsed // 2
-        e = np.exp(np.arange(half, dtype=np.float32) * np.float32(-(math.log(10000) / (half - 1))))
-        arg = np.float32(timestep) * e
-        emb = torch.from_numpy(np.concatenate([np.sin(arg), np.cos(arg)]).astype(np.float32)).to(self.dev).repeat(B, 1)
+        emb = self._step_embedding(int(timestep), half).repeat(B, 1)
         g = ops.gemm(emb, w["diffusion_step_encoder.1.weight"], bias=w["diffusion_step_encoder.1.bias"], prec=self.prec, b_scale=self.bs)
         g = ops.gemm(ops.mish(g), w["diffusion_step_encoder.3.weight"], bias=w["diffusion_step_encoder.3.bias"], prec=self.prec, b_scale=self.bs)
         gm = ops.mish(torch.cat([g, cond], dim=1).contiguous())            # every cond_encoder starts with the same Mish
@@ -328,3 +337,39 @@ class DiffusionNet:
             a_prev = float(self.ac[k - ratio]) if k - ratio >= 0 else 1.0
             ops.ddim_step(x, eps, a_t, a_prev, clip=True)
         return x
+
+    @_on_own_device
+    def capture_infer(self, batch, image_like):
+        """Capture one whole policy query (observation features + every DDIM step) into a hipGraph and return
+        ``replay(qpos, image, noise=None) -> actions``.  Eager, the query is ~1.3k op-level launches issued from Python (the
+        ten U-Net passes alone ~100 small launches each): the launch overhead, not the kernels, sets its time.  `image_like`
+        fixes the image format of the captured graph (u8 [B, cams, H, W, 3] or f32 [B, cams, 3, H, W])."""
+        if self.w is None:
+            raise RuntimeError("load_state_dict first")
+        dev = self.dev
+        s_qpos = torch.zeros((batch, self.S), dtype=torch.float32, device=dev)
+        s_img = torch.zeros((batch,) + tuple(image_like.shape[1:]), dtype=image_like.dtype, device=dev)
+        s_noise = torch.zeros((batch, self.T, self.A), dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                     # warm-up: function attributes, step embeddings, workspaces
+            self.forward_infer(s_qpos, s_img, noise=s_noise)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            s_out = self.forward_infer(s_qpos, s_img, noise=s_noise)
+
+        def replay(qpos, image, noise=None):
+            s_qpos.copy_(qpos, non_blocking=True)
+            s_img.copy_(image, non_blocking=True)
+            if noise is None:
+                s_noise.normal_()                         # the Gaussian start of policy.py:203-205, drawn outside the graph
+            else:
+                s_noise.copy_(noise, non_blocking=True)
+            graph.replay()
+            return s_out
+
+        replay.graph = graph
+        replay.static = (s_qpos, s_img, s_noise, s_out)
+        return replay

@@ -186,7 +186,16 @@ class DiffusionPolicy:
         if actions is not None:
             raise NotImplementedError("DiffusionPolicy training is outside the accelerated path (SURVEY 8 f2): inference only")
         # u8 NHWC [B, cams, H, W, 3] (fast path) or the reference contract f32 [B, cams, 3, H, W] in [0, 1]
-        # (imitate_episodes.py:206-225; the eval-time crop + resize makes it non-integer, so it is NOT re-quantised)
+        # (imitate_episodes.py:206-225; the eval-time crop + resize makes it non-integer, so it is NOT re-quantised).
+        # The whole query (observation trunk + every DDIM step) replays as ONE captured hipGraph per (batch, image format);
+        # ACTMI_DIFFUSION_GRAPH=0 issues its ~1.3k launches eagerly
+        import os
+        if os.environ.get("ACTMI_DIFFUSION_GRAPH", "1") != "0":
+            key = (int(qpos.shape[0]), image.dtype, tuple(image.shape[1:]))
+            graphs = self.__dict__.setdefault("_graphs", {})
+            if key not in graphs:
+                graphs[key] = self.model.capture_infer(key[0], image)
+            return graphs[key](qpos, image, noise=noise).clone()
         return self.model.forward_infer(qpos, image, noise=noise)
 
     def cuda(self):
@@ -209,5 +218,6 @@ class DiffusionPolicy:
 
     def deserialize(self, model_dict):
         src = model_dict.get("ema") or model_dict["nets"]          # inference runs the EMA copy (policy.py:184-186)
+        self.__dict__.pop("_graphs", None)                         # captured graphs hold the old prepared weights
         missing, unexpected = self.model.load_state_dict(src, strict=True)
         return _LoadStatus(missing, unexpected)

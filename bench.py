@@ -611,7 +611,16 @@ def diffusion_record(dev, B, iters, warmup):
     for _ in range(iters):
         out = net.forward_infer(qpos, img, noise=noise)
     torch.cuda.synchronize(dev)
-    dt = (time.perf_counter() - t0) / iters
+    dt_eager = (time.perf_counter() - t0) / iters
+    replay = net.capture_infer(B, img)                  # the whole query as one hipGraph (what DiffusionPolicy.__call__ runs)
+    out_g = replay(qpos, img, noise=noise)
+    torch.cuda.synchronize(dev)
+    assert torch.equal(out_g, out), "graph replay differs from eager launches"
+    t0 = time.perf_counter()
+    for _ in range(iters * 3):
+        out = replay(qpos, img, noise=noise)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / (iters * 3)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     cond = net.obs_cond(qpos, img)
     e0.record()
@@ -620,7 +629,8 @@ def diffusion_record(dev, B, iters, warmup):
     torch.cuda.synchronize(dev)
     assert torch.isfinite(out).all()
     return {"per_gpu_batch": B, "cameras": len(cams), "prediction_horizon": 32, "ddim_steps": 10, "ms_per_query_batch": dt * 1e3,
-            "policy_steps_per_s": B / dt, "unet_pass_ms": e0.elapsed_time(e1), "launch": "eager (op-level C ABI calls from Python)",
+            "policy_steps_per_s": B / dt, "unet_pass_ms_eager": e0.elapsed_time(e1), "ms_per_query_batch_eager": dt_eager * 1e3,
+            "launch": "hipGraph replay of the whole query (eager: op-level C ABI calls from Python)",
             "parity": "unpinned: robomimic / diffusers restated from their published definitions (not importable offline)"}
 
 

@@ -139,3 +139,28 @@ def test_policy_wrapper_surface():
     assert torch.equal(pol2(q, img, noise=noise), a)
     with pytest.raises(NotImplementedError):
         pol(q, img, actions=torch.zeros(1, 16, 16, device=D), is_pad=torch.zeros(1, 16, dtype=torch.bool, device=D))
+
+
+def test_whole_query_graph_replay_equals_eager_launches():
+    """DiffusionNet.capture_infer: observation trunk + all DDIM steps as ONE hipGraph (the step loop was
+    issued op by op from Python).  Replays are bit-identical to eager launches, for fresh inputs too, in both image formats."""
+    from actmi import weights as W
+    cams, B, T, H, Wd = ["a", "b"], 3, 16, 64, 96
+    net = DiffusionNet(cams, prediction_horizon=T)
+    net.load_state_dict(generate_diffusion_state_dict(diffusion_state_dict_spec(cams), seed=8))
+    g = torch.Generator().manual_seed(0)
+    for fmt in ("u8", "f32"):
+        img0 = torch.from_numpy(W.rand_u8(3, "gimg", (B, len(cams), H, Wd, 3))).to(D)
+        if fmt == "f32":
+            img0 = img0.permute(0, 1, 4, 2, 3).float().div(255.0).contiguous()
+        replay = net.capture_infer(B, img0)
+        for trial in range(3):
+            qpos = torch.randn(B, 14, generator=g).to(D)
+            noise = torch.randn(B, T, 16, generator=g).to(D)
+            img = img0 if trial == 0 else (img0.flip(0).contiguous())
+            exp = net.forward_infer(qpos, img, noise=noise)
+            got = replay(qpos, img, noise=noise)
+            assert torch.equal(got, exp), (fmt, trial)
+        r1 = replay(qpos, img).clone()                    # no noise given: a fresh Gaussian start per call
+        r2 = replay(qpos, img).clone()
+        assert not torch.equal(r1, r2) and torch.isfinite(r1).all()
