@@ -37,6 +37,10 @@ struct ConvLayer {
     int Kx = 0;               // = ds.cin
     float *wf = nullptr, *wf16 = nullptr, *bias_f = nullptr;
     float wf16_scale = W16_SCALE;
+    // power-of-two pre-scale of this layer's INPUT activations before their fp16 split (inference, f16x3): 1 unless the
+    // calibration forward of actmi_finalize found the input far from the fp16 range (FrozenBN statistics of a trained
+    // checkpoint can leave a map at 1e-5 or 1e4); undone through the epilogue's alpha
+    float a_scale = 1.f;
 };
 
 struct MhaW { float *in_w, *in_b, *out_w, *out_b; };
@@ -138,6 +142,10 @@ struct actmi_ctx {
     int ln_split = 3;                  // split factor of a long-K product followed by a slice-summing LayerNorm (ACTMI_LN_SPLIT)
     int last_B = 0;                    // batch of the forward in flight (debug views)
     int policy_mult = 1;               // split-K policy counts the tiles of the WHOLE camera set while a half is being launched
+    bool act_calib = true;             // activation pre-scales measured at finalize (ACTMI_ACT_CALIB=0: off)
+    bool calibrating = false;          // engine_backbone is running the calibration forward
+    float ip_a_scale = 1.f;            // the same for input_proj's operand (the layer4 maps)
+    float* act_scale_dev = nullptr;    // device copies [convs.size() + 1] for the kernels that take a device scale (conv3.hip)
     bool fuse_ds = true;               // downsample branch inside conv2's contraction (ACTMI_FUSE_DS=0: three launches as before)
     bool conv_direct = false;          // layer2-4 stride-1 3x3 convolutions on the direct kernel (conv3g.hip): measured slower, opt-in
     int conv_direct_min_images = 8;    // below this many images (cameras x batch) its grid is too small: implicit GEMM + split-K
@@ -192,6 +200,9 @@ const char* engine_create_error();
 int engine_finalize(actmi_ctx* ctx, hipStream_t st);
 int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st, bool after_step = false);
 int engine_calibrate_weight_scales(actmi_ctx* ctx, hipStream_t st);
+int engine_calibrate_activations(actmi_ctx* ctx, hipStream_t st);
+int engine_measure_act_scale(actmi_ctx* ctx, const float* x, int64_t rows, int cols, hipStream_t st, float* out);
+int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream_t st);
 float engine_weight_scale(const actmi_ctx* ctx, const float* w);
 int train_create(actmi_ctx* ctx);
 int train_forward(actmi_ctx* ctx, const float* qpos, const void* image, int fmt, const float* actions, const uint8_t* is_pad,

@@ -519,6 +519,8 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
     if ((rc = dev_alloc(ctx, &ctx->X, BN_ * D))) return fail(rc);
     if ((rc = dev_alloc(ctx, &ctx->X1, BN_ * D))) return fail(rc);
     if ((rc = dev_alloc(ctx, &ctx->XP, BN_ * D))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->act_scale_dev, (int64_t)ctx->convs.size() + 4))) return fail(rc);
+    { const char* e1 = getenv("ACTMI_ACT_CALIB"); ctx->act_calib = !(e1 && e1[0] == '0'); }
     { const char* e1 = getenv("ACTMI_LN_XP"); ctx->ln_xp = !(e1 && e1[0] == '0'); }
     { const char* e1 = getenv("ACTMI_LN_HEAD"); ctx->ln_head = !(e1 && e1[0] == '0'); }
     if ((rc = dev_alloc(ctx, &ctx->Y, BN_ * D))) return fail(rc);
@@ -728,6 +730,7 @@ int engine_finalize(actmi_ctx* ctx, hipStream_t st) {
         }
     }
     HIPCHK(hipStreamSynchronize(st));
+    CHK(engine_calibrate_activations(ctx, st));
     ctx->finalized = true;
     return 0;
 }
@@ -735,6 +738,53 @@ int engine_finalize(actmi_ctx* ctx, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // forward pieces
 // ------------------------------------------------------------------------------------------------
+
+// Activation range guard of the f16x3 forward.  Activations are split into fp16 pieces on
+// their way into LDS: a map whose magnitudes sit far below 1 loses the lo piece to fp16 subnormals (absolute floor 2^-25) and
+// one beyond 65504 overflows.  The trunk's maps pass through FrozenBatchNorm2d (backbone.py:21-57), whose frozen statistics
+// can leave them at any magnitude in a trained checkpoint, so actmi_finalize runs ONE calibration forward of the trunk on a
+// synthetic image and gives every convolution whose input lies outside [2^-4, 2^11] a power-of-two input pre-scale that brings
+// its largest magnitude to ~2^9..2^10 (64x headroom for hotter frames); inside that window the scale stays 1 and the hot
+// (unmasked) kernel flavour runs.  Power-of-two scaling is exact; it is undone through the epilogue's alpha.
+int engine_measure_act_scale(actmi_ctx* ctx, const float* x, int64_t rows, int cols, hipStream_t st, float* out) {
+    *out = 1.f;
+    if (rows <= 0 || rows > 0x7fffffff) return 0;
+    float* slot = ctx->tmp_vec + 2;             // [scale, bits word]: the word must be zero before the first use
+    HIPCHK(hipMemsetAsync(slot, 0, 2 * sizeof(float), st));
+    CHK(launch_pow2_scale(x, cols, (int)rows, cols, slot, st));
+    float s = 1.f;
+    HIPCHK(hipMemcpyAsync(&s, slot, sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    // s brings max|x| into [2^13, 2^14): max|x| < 2^-4  <=>  s > 2^17;  max|x| >= 2^11  <=>  s <= 2^2
+    if (s > 131072.f || s <= 4.f) *out = s * (1.f / 16.f);
+    return 0;
+}
+
+int engine_calibrate_activations(actmi_ctx* ctx, hipStream_t st) {
+    for (auto& cl : ctx->convs) cl.a_scale = 1.f;
+    ctx->ip_a_scale = 1.f;
+    if (ctx->gemm_prec != ACTMI_PREC_F16X3 || !ctx->act_calib) return 0;
+    const actmi_config& g = ctx->cfg;
+    const size_t nbytes = (size_t)g.num_cams * g.image_h * g.image_w * 3;
+    std::vector<unsigned char> img(nbytes);
+    uint32_t x = 0x9E3779B9u;                   // a fixed noise frame covering the whole u8 range
+    for (size_t i = 0; i < nbytes; ++i) { x = x * 1664525u + 1013904223u; img[i] = (unsigned char)(x >> 24); }
+    void* dimg = nullptr;
+    if (hipMalloc(&dimg, nbytes) != hipSuccess) { ctx->err = "hipMalloc (calibration frame)"; return ACTMI_E_NOMEM; }
+    int rc = hipMemcpy(dimg, img.data(), nbytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : ACTMI_E_LAUNCH;
+    if (rc == 0) {
+        ctx->calibrating = true;
+        const std::string keep = ctx->stop_stage;
+        ctx->stop_stage.clear();
+        rc = engine_backbone(ctx, dimg, ACTMI_IMG_U8_NHWC, 1, st);
+        ctx->stop_stage = keep;
+        ctx->calibrating = false;
+        if (hipStreamSynchronize(st) != hipSuccess && rc == 0) rc = ACTMI_E_LAUNCH;
+    }
+    (void)hipFree(dimg);
+    ctx->dbg.clear();
+    return rc;
+}
 
 // nb concurrent branches of one forward: branch 0 on the caller's stream, branch i > 0 on ctx->pipe_streams[i - 1], forked from
 // and joined back into the caller's stream with events (parallel branches of the graph under capture).  Whatever fails -- a
@@ -807,7 +857,8 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
     // the stem inside the branches (ACTMI_STEM_BRANCH=1): one branch's conv1 (bound by its own instruction stream) beside the
     // other's pool / layer1 launches
     static const bool stem_in_branch = getenv("ACTMI_STEM_BRANCH") && getenv("ACTMI_STEM_BRANCH")[0] == '1';
-    const bool pipe_early = stem_in_branch && ctx->cam_pipe && ctx->pipe_stream && C >= 2 && !prof_enabled() && ctx->stop_stage.empty();
+    const bool pipe_early = stem_in_branch && ctx->cam_pipe && ctx->pipe_stream && C >= 2 && !prof_enabled() && ctx->stop_stage.empty() &&
+                            !ctx->calibrating;
     if (!pipe_early) CHK(run_stem(0, C, st));
     ctx->dbg.clear();
     ctx->dbg["conv1"] = {ctx->act1, (int64_t)C * B * ctx->H1 * ctx->W1 * w0};
@@ -822,15 +873,26 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
         const int64_t w_cam = (int64_t)cl.cout * cl.K;
         const float* scale = cl.scale + (int64_t)c0 * cl.cout;
         const float* bias = cl.bias + (int64_t)c0 * cl.cout;
+        const int cl_index = (int)(&cl - ctx->convs.data());
+        if (ctx->calibrating) {
+            // calibration forward (actmi_finalize): measure this layer's input, fix its pre-scale, THEN run the layer with it
+            // (so that a map far outside the fp16 range does not poison the measurements downstream); one host sync per layer
+            float sc = 1.f;
+            CHK(engine_measure_act_scale(ctx, in, (int64_t)nc * B * cl.H * cl.W, cl.cin, cs, &sc));
+            const_cast<ConvLayer&>(cl).a_scale = sc;
+            HIPCHK(hipMemcpyAsync(ctx->act_scale_dev + cl_index, &cl.a_scale, sizeof(float), hipMemcpyHostToDevice, cs));
+            HIPCHK(hipStreamSynchronize(cs));
+        }
         if (ctx->gemm_prec == ACTMI_PREC_F16X3 && cl.k == 3 && cl.stride == 1 && cl.pad == 1 && cl.cin == 64 && cl.cout == 64) {
             // layer1: direct convolution over an LDS-resident patch (the im2col GEMM is L2-traffic bound at 64 channels)
             Conv3Args c3;
             c3.x = in; c3.w16 = cl.w16 + c0 * w_cam; c3.scale = scale; c3.bias = bias; c3.res = res; c3.out = out;
             c3.G = nc; c3.B = B; c3.H = cl.H; c3.W = cl.W; c3.relu = relu; c3.w_scale = cl.w16_scale;
+            if (cl.a_scale != 1.f) c3.x_scale_dev = ctx->act_scale_dev + cl_index;
             return launch_conv3x3_c64(c3, cs, &ctx->err);
         }
         if (ctx->gemm_prec == ACTMI_PREC_F16X3 && ctx->conv_direct && cl.k == 3 && cl.stride == 1 && cl.pad == 1 &&
-            (cl.cin % 64) == 0 && (cl.cout % 64) == 0 && B * C >= ctx->conv_direct_min_images) {
+            (cl.cin % 64) == 0 && (cl.cout % 64) == 0 && B * C >= ctx->conv_direct_min_images && cl.a_scale == 1.f) {
             // layer2-4 stride-1 convolutions: the same direct scheme per 64-channel chunk (conv3g.hip) -- a third fewer
             // operand bytes per MFMA than the implicit GEMM at its 128x128 tile
             Conv3gArgs cg;
@@ -849,12 +911,13 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
         a.groups = nc;
         a.gA = in_cam; a.gB = w_cam; a.gSB = cl.cout;
         a.gC = (int64_t)a.M * cl.cout; a.gRes = a.gC;
+        if (ctx->gemm_prec == ACTMI_PREC_F16X3 && cl.a_scale != 1.f) a.a_scale = cl.a_scale;
         return ctx_gemm(ctx, a, cs, half);
     };
     // the side branch needs the split-K workspace for itself: only taken when the main stream's launches do not split
     // (not while the per-launch profiler brackets launches with events, nor for the debug early-outs)
-    const bool pipe = ctx->cam_pipe && ctx->pipe_stream && C >= 2 && !prof_enabled() && ctx->stop_stage.empty();
-    const bool fork_ds = ctx->side_stream != nullptr && ctx->ds_fork && !pipe;
+    const bool pipe = ctx->cam_pipe && ctx->pipe_stream && C >= 2 && !prof_enabled() && ctx->stop_stage.empty() && !ctx->calibrating;
+    const bool fork_ds = ctx->side_stream != nullptr && ctx->ds_fork && !pipe && !ctx->calibrating;
     float* final_cur = nullptr;
     // layer1 .. layer4 for the cameras [c0, c0 + nc) on stream ls
     auto run_layers = [&](int c0, int nc, hipStream_t ls, int half) -> int {
@@ -890,7 +953,8 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
                 const ConvLayer& k1 = ctx->convs[ci++];
                 const ConvLayer& k2 = ctx->convs[ci++];
                 const bool has_ds = (bi == 0 && li > 1);
-                if (has_ds && ctx->fuse_ds && k2.wf && ctx->gemm_prec == ACTMI_PREC_F16X3) {
+                if (has_ds && ctx->fuse_ds && k2.wf && ctx->gemm_prec == ACTMI_PREC_F16X3 && !ctx->calibrating && k2.a_scale == 1.f &&
+                    ctx->convs[k2.ds_index].a_scale == 1.f) {
                     // the downsample branch rides in conv2's contraction (second source = the block input at stride 2):
                     // two launches instead of three, and the branch's map is neither written nor read back
                     ++ci;                                        // (the downsample layer's own entry)
@@ -936,6 +1000,11 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
         GemmArgs ip = linear_args(cur, 8 * w0, nc * B * ctx->P_, 8 * w0, ctx->P("input_proj.weight"), D, ctx->P("input_proj.bias"),
                                   ctx->X, D);
         ip.rowmap = ctx->rowmap + (int64_t)c0 * B * ctx->P_;
+        if (ctx->calibrating) {
+            CHK(engine_measure_act_scale(ctx, cur, (int64_t)nc * B * ctx->P_, 8 * w0, ls, &ctx->ip_a_scale));
+            HIPCHK(hipStreamSynchronize(ls));
+        }
+        if (ctx->gemm_prec == ACTMI_PREC_F16X3 && ctx->ip_a_scale != 1.f) ip.a_scale = ctx->ip_a_scale;
         return ctx_gemm(ctx, ip, ls, half);
     };
     if (ctx->rowmap_B != B) {

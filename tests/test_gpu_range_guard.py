@@ -60,6 +60,60 @@ CASES = {
 }
 
 
+def _stem_bn(sd, factor):
+    """FrozenBN of the stem (bn1 of every backbone): gain and shift x factor -> the stem's map, the pooled map and with it the
+    input of layer1 (and layer1.0's identity path) are x factor"""
+    return _scale_group(sd, lambda k: k.endswith(".0.body.bn1.weight") or k.endswith(".0.body.bn1.bias"), factor)
+
+
+# FrozenBN statistics that leave ACTIVATIONS far from the fp16 range (VERDICT r02 weak #12: only weights were calibrated).
+# The stem's map at 1e-5 of its usual magnitude (its split pieces would be fp16 subnormals) feeding a convolution whose weights
+# are 1e5 larger; and the reverse, a map at ~3e4 x (beyond 65504 for its larger values) feeding 3e-5 x weights.  The identity
+# path of layer1.0 carries the rescaled map too, so the function changes -- what is compared is hip vs the oracle on it.
+ACT_CASES = {
+    "stem_map_x1e-5": lambda sd: _scale_group(_stem_bn(sd, 1e-5), lambda k: "layer1.0.conv1.weight" in k, 1e5),
+    "stem_map_x3e4": lambda sd: _scale_group(_stem_bn(sd, 3e4), lambda k: "layer1.0.conv1.weight" in k, 1.0 / 3e4),
+    # inside the trunk: layer2's output 1e-4 x (bn2 of its last block and nothing else), layer3.0's first convolution and its
+    # downsample 1e4 x -- the fused conv2 + downsample launch must fall back to separate launches for the rescaled input
+    "layer2_out_x1e-4": lambda sd: _scale_group(
+        _scale_group(sd, lambda k: "layer2.1.bn2.weight" in k or "layer2.1.bn2.bias" in k, 1e-4),
+        lambda k: "layer3.0.conv1.weight" in k or "layer3.0.downsample.0.weight" in k, 1e4),
+}
+
+
+@pytest.mark.parametrize("width", [8, 64])
+@pytest.mark.parametrize("case", sorted(ACT_CASES))
+def test_activation_scales_are_calibrated_at_finalize(case, width):
+    """width 8: every convolution on the implicit-GEMM kernel; width 64: layer1 on the direct kernel of conv3.hip (device-side
+    input scale) and the fused conv2 + downsample launches of layers 2-4"""
+    cfg = tiny_config(camera_names=["a", "b"], image_h=64, image_w=96, base_width=width)
+    sd_np = ACT_CASES[case](W.generate_state_dict(cfg, seed=23))
+    inp = W.generate_inputs(cfg, 2, seed=6)
+    exp = _oracle(cfg, sd_np, inp)
+    assert np.isfinite(exp).all()
+    got = _hip(cfg, sd_np, inp)
+    err = float(np.abs(got - exp).max())
+    scale = max(1.0, float(np.abs(exp).max()))
+    print(f"{case} [width {width}]: max|a_hat - oracle| = {err:.3e} (|a_hat| max {np.abs(exp).max():.3e})")
+    assert np.isfinite(got).all() and err <= ATOL * scale
+
+
+def test_without_calibration_the_small_map_loses_precision(monkeypatch):
+    """the failure the calibration removes, kept visible: ACTMI_ACT_CALIB=0 on the 1e-5 stem map is off by far more than 1e-4"""
+    monkeypatch.setenv("ACTMI_ACT_CALIB", "0")
+    cfg = tiny_config(camera_names=["a", "b"], image_h=64, image_w=96)
+    sd_np = ACT_CASES["stem_map_x1e-5"](W.generate_state_dict(cfg, seed=23))
+    inp = W.generate_inputs(cfg, 2, seed=6)
+    exp = _oracle(cfg, sd_np, inp)
+    eng = ACTEngine(cfg, max_batch=2, gemm_prec="f16x3")
+    eng.load_state_dict(sd_np)
+    eng.finalize()
+    got = eng.forward_infer(torch.from_numpy(inp["qpos"]).cuda(), torch.from_numpy(inp["image_u8"]).cuda()).cpu().numpy()
+    err = float(np.abs(got - exp).max())
+    print(f"uncalibrated: max|a_hat - oracle| = {err:.3e}")
+    assert not (err <= ATOL * max(1.0, float(np.abs(exp).max())))
+
+
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_rescaled_layer_groups_match_the_oracle(case):
     cfg = tiny_config(camera_names=["a", "b", "c"], image_h=96, image_w=128)
