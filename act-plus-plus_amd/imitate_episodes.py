@@ -103,7 +103,7 @@ def _default_stats(state_dim, action_dim=16):
 
 def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, ensemble_factory=None,
             env_factory=None, stats=None, max_parallel=None, warmup_queries=0, realtime=False, verbose=True,
-            trace=None, vq_sampler=None):
+            trace=None, vq_sampler=None, pipeline_groups=None):
     """reference imitate_episodes.py:228-526, batched + sharded.  Returns (success_rate, avg_return).
 
     VQ-ACT: the reference samples the latent code from its prior model each query
@@ -198,61 +198,117 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
     DT = 1 / FPS
     t_policy, n_queries = 0.0, 0
     pool = ThreadPoolExecutor(max_workers=min(16, max(1, max_parallel)))
+    engine = getattr(policy, "model", None)
+    flags_dev = engine.flags_tensor() if (on_gpu and hasattr(engine, "flags_tensor")) else None
+
+    def _copy_frames(buf, e, ts):
+        for c, name in enumerate(camera_names):
+            buf[e, c] = ts.observation["images"][name]
+        return ts
+
     for w0 in range(lo, hi, max_parallel):
         ids = list(range(w0, min(hi, w0 + max_parallel)))
         E = len(ids)
         envs = [env_factory(poses[i], i) for i in ids]
         env_max_reward = envs[0].task.max_reward
-        ts_list = list(pool.map(lambda e: e.reset(), envs))
-        # the reference's Diffusion branch never ensembles (imitate_episodes.py:417-423): with temporal_agg it re-queries every
-        # step (query_frequency = 1) and takes the first action of the new chunk
-        ens = ensemble_factory(E) if (temporal_agg and not is_diffusion) else None
-        rewards = [[] for _ in range(E)]
-        pinned, all_actions = None, None
-        time0 = time.time()
-        for t in range(max_timesteps):
-            time1 = time.time()
+        # Two groups of episodes in ping-pong (GPU only): while the GPU runs the policy query of one group, the host steps the
+        # other group's simulators, gathers their frames into pinned memory and queues that group's next query -- the H2D copy,
+        # the forward and the D2H of the actions of a group are queued on the stream back to back and waited for with an event,
+        # never with a device-wide synchronisation.  Episodes are independent, so each one sees exactly the steps it would see
+        # alone (tests/test_gpu_rollout.py).  pipeline_groups=1 (or a CPU stand-in policy) keeps the single lock-step group.
+        G = 2 if (on_gpu and E >= 2 and pipeline_groups != 1 and not realtime) else 1
+        cuts = [0, E] if G == 1 else [0, (E + 1) // 2, E]
+        h, w, _ = None, None, None
+        groups = []
+        for gi in range(G):
+            sl = slice(cuts[gi], cuts[gi + 1])
+            g_envs = envs[sl]
+            g = {"ids": ids[sl], "envs": g_envs, "E": len(g_envs), "ens": None, "rewards": [[] for _ in g_envs], "pinned": None,
+                 "all_actions": None, "ev": torch.cuda.Event() if on_gpu else None, "raw_host": None, "flag_host": None, "tq": 0.0}
+            g["ens"] = ensemble_factory(g["E"]) if (temporal_agg and not is_diffusion) else None
+            g["ts"] = list(pool.map(lambda e: e.reset(), g_envs))
+            groups.append(g)
+
+        def enqueue(g, t):
+            """queue step t of a group: (H2D of its frames +) policy query + ensemble + D2H of the actions, then an event"""
+            nonlocal n_queries
+            ts_list = g["ts"]
             qpos_numpy = np.stack([np.array(ts.observation["qpos"]) for ts in ts_list])
-            qpos = torch.from_numpy(pre_process(qpos_numpy)).float().to(dev)
+            qpos = torch.from_numpy(pre_process(qpos_numpy)).float().to(dev, non_blocking=True)
+            g["tq"] = time.time()
             if t % query_frequency == 0:
-                pinned = get_image_batch_u8(ts_list, camera_names, pinned)
-                curr_image = pinned.to(dev, non_blocking=True)
+                if g["pinned"] is None or t == 0:
+                    g["pinned"] = get_image_batch_u8(ts_list, camera_names, g["pinned"])
+                curr_image = g["pinned"].to(dev, non_blocking=True)
                 if is_diffusion:
                     # get_image(..., rand_crop_resize=True) of the reference (:214-224, :374): f32 in [0, 1], centre 0.95 crop,
-                    # resized back -- on the device, for all E episodes at once
+                    # resized back -- on the device, for all episodes of the group at once
                     curr_image = center_crop_resize(curr_image.permute(0, 1, 4, 2, 3).float().div(255.0))
                 if t == 0:
                     for _ in range(warmup_queries):
                         policy(qpos, curr_image, vq_sample=vq_sampler(qpos.shape[0])) if use_vq else policy(qpos, curr_image)
-                tq = time.time()
-                all_actions = (policy(qpos, curr_image, vq_sample=vq_sampler(qpos.shape[0])) if use_vq
-                               else policy(qpos, curr_image))                # [E,Q,A]
-                n_queries += E
-            if ens is not None:
-                raw_action = ens.step(all_actions)                           # [E,A] float64, like the reference
+                g["all_actions"] = (policy(qpos, curr_image, vq_sample=vq_sampler(qpos.shape[0])) if use_vq
+                                    else policy(qpos, curr_image))            # [E_g,Q,A]
+                n_queries += g["E"]
+            if g["ens"] is not None:
+                raw = g["ens"].step(g["all_actions"])                        # [E_g,A] float64, like the reference
             else:
-                raw_action = all_actions[:, t % query_frequency]
-            raw_action = raw_action.cpu().numpy()                            # D2H sync, once per step for all E
-            if hasattr(getattr(policy, "model", None), "check_flags"):
-                policy.model.check_flags()                                   # range guard, read at this natural sync point
+                raw = g["all_actions"][:, t % query_frequency]
+            if on_gpu:
+                if g["raw_host"] is None or g["raw_host"].dtype != raw.dtype:
+                    g["raw_host"] = torch.empty(tuple(raw.shape), dtype=raw.dtype).pin_memory()
+                    g["flag_host"] = torch.zeros(1, dtype=torch.int32).pin_memory()
+                g["raw_host"].copy_(raw, non_blocking=True)
+                if flags_dev is not None:
+                    g["flag_host"].copy_(flags_dev, non_blocking=True)       # the range guard's word rides along: no extra sync
+                g["ev"].record()
+            else:
+                g["raw_host"] = raw
+
+        def finish(g, t):
+            """wait for step t of a group, step its simulators (frames of the next query straight into pinned memory)"""
+            nonlocal t_policy
+            if on_gpu:
+                g["ev"].synchronize()                                        # this group's actions are on the host
+                if flags_dev is not None and int(g["flag_host"][0]) != 0:
+                    engine.check_flags()                                     # raises with the reason (and clears the word)
+            raw_action = g["raw_host"].numpy().copy() if on_gpu else g["raw_host"].cpu().numpy()
             if t % query_frequency == 0:
-                t_policy += time.time() - tq
+                t_policy += time.time() - g["tq"]
             if trace is not None:
-                trace.append((ids, t, raw_action.copy()))
+                trace.append((g["ids"], t, raw_action.copy()))
             action = post_process(raw_action)
             target_qpos = action[:, :-2]
-            ts_list = list(pool.map(lambda p: p[0].step(p[1]), zip(envs, target_qpos)))
-            for e in range(E):
-                rewards[e].append(ts_list[e].reward)
+            need_frames = (t + 1) % query_frequency == 0 and g["pinned"] is not None and t + 1 < max_timesteps
+            buf = g["pinned"].numpy() if need_frames else None
+
+            def step_one(p):
+                e, env, a = p
+                ts = env.step(a)
+                return _copy_frames(buf, e, ts) if buf is not None else ts
+            g["ts"] = list(pool.map(step_one, zip(range(g["E"]), g["envs"], target_qpos)))
+            for e in range(g["E"]):
+                g["rewards"][e].append(g["ts"][e].reward)
+
+        time0 = time.time()
+        for g in groups:
+            enqueue(g, 0)
+        for t in range(max_timesteps):
+            time1 = time.time()
+            for g in groups:
+                finish(g, t)
+                if t + 1 < max_timesteps:
+                    enqueue(g, t + 1)
             if realtime:
                 time.sleep(max(0, DT - (time.time() - time1)))
         if verbose:
             print(f"rank {rank}: episodes {ids[0]}..{ids[-1]} avg fps {max_timesteps / (time.time() - time0):.1f} "
-                  f"({E} parallel episodes)")
-        for e, i in enumerate(ids):
-            r = np.array(rewards[e])
-            episode_return = float(np.sum(r[r != None]))                      # noqa: E711  (reference :499)
-            local_results.append([episode_return, float(np.max(r))])
+                  f"({E} parallel episodes{', two ping-pong groups' if G == 2 else ''})")
+        for g in groups:
+            for e, i in enumerate(g["ids"]):
+                r = np.array(g["rewards"][e])
+                episode_return = float(np.sum(r[r != None]))                  # noqa: E711  (reference :499)
+                local_results.append([episode_return, float(np.max(r))])
     pool.shutdown()
 
     local = torch.tensor(local_results, dtype=torch.float32).reshape(-1, 2)

@@ -57,6 +57,15 @@ def test_batched_rollout_matches_sequential_oracle(tmp_path):
             ts = env.step(raw[:-2])
     print(f"rollout: max|raw_action - sequential oracle| = {worst:.3e}")
     assert worst <= 1e-4
+    # the default above ran the three episodes as two ping-pong groups (2 + 1, the policy query of one beside the simulator
+    # steps of the other); one lock-step group gives the same trajectories (other batch sizes pick other tile shapes: 3e-5)
+    assert any(len(ids) < n for ids, _, _ in trace)
+    trace1 = []
+    res1 = IE.eval_bc(config, "policy_last.ckpt", num_rollouts=n, policy=policy, env_factory=env_factory, verbose=False,
+                      trace=trace1, pipeline_groups=1)
+    assert all(len(ids) == n for ids, _, _ in trace1) and res1 == res
+    got1 = {(i, t): row for ids, t, raw in trace1 for i, row in zip(ids, raw)}
+    assert got1.keys() == got.keys() and max(float(np.abs(got1[k] - got[k]).max()) for k in got) <= 3e-5
 
 
 @pytest.mark.filterwarnings("ignore::DeprecationWarning")        # torch's own pin_memory helper
