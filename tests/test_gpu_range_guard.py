@@ -66,18 +66,31 @@ def _stem_bn(sd, factor):
     return _scale_group(sd, lambda k: k.endswith(".0.body.bn1.weight") or k.endswith(".0.body.bn1.bias"), factor)
 
 
-# FrozenBN statistics that leave ACTIVATIONS far from the fp16 range (only weights were calibrated).
-# The stem's map at 1e-5 of its usual magnitude (its split pieces would be fp16 subnormals) feeding a convolution whose weights
-# are 1e5 larger; and the reverse, a map at ~3e4 x (beyond 65504 for its larger values) feeding 3e-5 x weights.  The identity
-# path of layer1.0 carries the rescaled map too, so the function changes -- what is compared is hip vs the oracle on it.
+# Checkpoints whose ACTIVATIONS sit far from the fp16 range (only weights were calibrated): maps at 1e-5 x
+# (their split pieces would be fp16 subnormals) or 1e4 x (beyond 65504 for the larger values) of the usual magnitude.  The
+# rescaled identity paths change the function -- what is compared is hip vs the oracle on the same state_dict.  The token
+# stream of the transformer stays at its usual magnitude (LayerNorm keeps it there in any checkpoint).
+def _trunk_from_layer3(sd, f):
+    """every map from layer3 on x f (the first convolution and the downsample of layer3.0 carry the factor; FrozenBN does not
+    renormalise, so it persists to the trunk's output), input_proj / f restores the tokens' magnitude"""
+    return _scale_group(_scale_group(sd, lambda k: "layer3.0.conv1.weight" in k or "layer3.0.downsample.0.weight" in k, f),
+                        lambda k: k == "input_proj.weight", 1.0 / f)
+
+
 ACT_CASES = {
+    # the stem's map (and layer1.0's identity path) at 1e-5 of its usual magnitude, layer1.0.conv1 1e5 x larger
     "stem_map_x1e-5": lambda sd: _scale_group(_stem_bn(sd, 1e-5), lambda k: "layer1.0.conv1.weight" in k, 1e5),
-    "stem_map_x3e4": lambda sd: _scale_group(_stem_bn(sd, 3e4), lambda k: "layer1.0.conv1.weight" in k, 1.0 / 3e4),
-    # inside the trunk: layer2's output 1e-4 x (bn2 of its last block and nothing else), layer3.0's first convolution and its
-    # downsample 1e4 x -- the fused conv2 + downsample launch must fall back to separate launches for the rescaled input
-    "layer2_out_x1e-4": lambda sd: _scale_group(
-        _scale_group(sd, lambda k: "layer2.1.bn2.weight" in k or "layer2.1.bn2.bias" in k, 1e-4),
-        lambda k: "layer3.0.conv1.weight" in k or "layer3.0.downsample.0.weight" in k, 1e4),
+    # the reverse; the identity path keeps every later map at ~3e4 x, input_proj / 3e4 brings the tokens back
+    "stem_map_x3e4": lambda sd: _scale_group(_scale_group(_stem_bn(sd, 3e4), lambda k: "layer1.0.conv1.weight" in k, 1.0 / 3e4),
+                                             lambda k: k == "input_proj.weight", 1.0 / 3e4),
+    # inside the trunk, both directions: the fused conv2 + downsample launches must fall back to separate launches for the
+    # rescaled inputs, input_proj's operand gets a pre-scale of its own
+    "layer3_on_x1e4": lambda sd: _trunk_from_layer3(sd, 1e4),
+    # small in the middle of a downsample block: layer3.0's first map at 1e-4 x (its FrozenBN gain and shift), conv2 1e4 x larger
+    # -- the two sources of the fused conv2 + downsample contraction then differ by 1e4 in magnitude
+    "layer3_0_mid_x1e-4": lambda sd: _scale_group(
+        _scale_group(sd, lambda k: "layer3.0.bn1.weight" in k or "layer3.0.bn1.bias" in k, 1e-4),
+        lambda k: "layer3.0.conv2.weight" in k, 1e4),
 }
 
 
