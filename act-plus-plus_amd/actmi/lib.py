@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (must be loaded first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libactmi.so")
+# ACTMI_LIB: another build of the library (A/B runs of two builds on one GPU box: tools/ab_bench.sh); default: the in-tree one
+LIB_PATH = os.environ.get("ACTMI_LIB") or os.path.join(_HERE, "libactmi.so")
 
 IMG_U8_NHWC = 0
 IMG_F32_NCHW = 1

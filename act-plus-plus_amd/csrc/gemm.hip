@@ -187,8 +187,18 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
     // A_CONV fast path (block-uniform): when Cin is a multiple of the K tile, a K tile lies inside ONE filter tap, so the
     // tap (r,s) and its channel base are scalars per tile and the per-row work shrinks to a mask-bit test and one add
     // (the general path decomposes k per thread with two integer divisions per K tile).
-    const bool conv_fast = AMODE == A_CONV && (p.Cin % BK) == 0 && p.KH * p.KW <= 32 &&
-                           (int64_t)p.H * p.W * p.Cin < ((int64_t)1 << 30);
+    // CF: the hot (unmasked) convolution flavour ASSUMES the uniform-tap fast path (the host only selects it then, launch_cfg_b):
+    // the general im2col decode and its block-uniform branches are not even compiled into it, so the K step stays ONE basic
+    // block and the scheduler can weave the next tiles' loads between the MFMAs.  In this flavour all operand addresses are a
+    // uniform base + an unsigned 32-bit byte offset per lane (global_load with an SGPR base: no 64-bit VALU adds per load), and
+    // the filter tap of a K tile is tracked incrementally in scalar registers (the reciprocal-multiply decode cost ~15 VALU
+    // per tile on uniform values).  Measured on the round-2 build: 108 VALU per K tile and wave in this loop against 24 MFMAs.
+    constexpr bool CF = AMODE == A_CONV && UNMASKED != 0;
+    // SA: the same addressing (uniform base + unsigned 32-bit byte offset per lane) for the row-major hot flavours
+    constexpr bool SA = (AMODE == A_N || AMODE == A_NADD) && BMODE == B_N && UNMASKED != 0;
+    const bool conv_fast = CF || (AMODE == A_CONV && (p.Cin % BK) == 0 && p.KH * p.KW <= 32 &&
+                                  (int64_t)p.H * p.W * p.Cin < ((int64_t)1 << 30));
+    unsigned sa_offb[SA ? NLA : 1], sa_addb[(SA && AMODE == A_NADD) ? NLA : 1];
     unsigned a_tapmask[AMODE == A_CONV ? NLA : 1];
     int a_off0[AMODE == A_CONV ? NLA : 1];
     int a_offx[XS ? NLA : 1];                   // XS: this row's pixel of the second source (floats from Axg), + cidx * 4
@@ -220,6 +230,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                 const int64_t ar = p.a_rowmap ? p.a_rowmap[mm] : mm;
                 a_ptr[i] = A + ar * p.lda;
                 if (AMODE == A_NADD) add_ptr[i] = p.A_add + (int64_t)(mm % p.add_mod) * p.ld_add;
+                if (SA) {
+                    sa_offb[i] = ((unsigned)ar * (unsigned)p.lda + (unsigned)(cidx * 4)) * 4u;
+                    if (AMODE == A_NADD) sa_addb[i] = ((unsigned)(mm % p.add_mod) * (unsigned)p.ld_add + (unsigned)(cidx * 4)) * 4u;
+                }
             } else if (AMODE == A_CONV) {
                 const int hw = p.Ho * p.Wo;
                 const int b = mm / hw, rem = mm - b * hw;
@@ -238,6 +252,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                     const unsigned rowsel = (unsigned)((((uint64_t)1 << (r_hi * p.KW)) - 1u) & ~(((uint64_t)1 << (r_lo * p.KW)) - 1u));
                     a_tapmask[i] = a_ok[i] ? (rowsel & (colmask * conv_rep)) : 0u;
                     a_off0[i] = (a_hi0[i] * p.W + a_wi0[i]) * p.Cin + cidx * 4;
+                    if (CF) a_off0[i] += b * (int)p.img_stride;          // CF: offsets from the group's base, image included
                     if (XS) a_offx[i] = ((b * p.Hx + ho * p.stride_x) * p.Wx + wo * p.stride_x) * p.Cx + cidx * 4;
                 }
             } else {   // A_DGRAD: rows are input pixels (b, hi, wi)
@@ -257,12 +272,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
     int wg_r = 0, wg_s = 0, wg_c = 0;        // B_WGRAD: this thread's (r, s, c0) of its 4 out columns
     const float wg_inv_hw = (BMODE == B_WGRAD) ? 1.0f / (float)(p.Ho * p.Wo) : 0.f;
     const float wg_inv_wo = (BMODE == B_WGRAD) ? 1.0f / (float)p.Wo : 0.f;
+    unsigned b_offb[(CF || SA) ? NLB : 1];   // CF / SA: byte offset of this lane's row (and 16-byte chunk) from Bw
     if (BMODE == B_N) {
 #pragma unroll
         for (int i = 0; i < NLB; ++i) {
             const int n = n0 + srow + RPP * i;
             b_ok[i] = n < p.N;
             b_ptr[i] = Bw + (int64_t)(b_ok[i] ? n : 0) * p.ldb;
+            if (CF || SA) b_offb[i] = ((unsigned)(b_ok[i] ? n : 0) * (unsigned)p.ldb + (unsigned)(cidx * 4)) * 4u;
         }
     } else if (BMODE == B_WGRAD) {
         const int j0 = n0 + b_og * 4;
@@ -279,6 +296,18 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
     };
     Regs R0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // CF: the tile the loader was last asked for and its filter tap, kept in scalar registers.  The loader is called with
+    // non-decreasing tile numbers that grow by at most one (tail requests are clamped to the last tile).
+    int cf_kt = 0, cf_rs = 0, cf_r = 0, cf_q = 0, cf_cb = 0;
+    if (CF) {
+        const int tpr = p.Cin / BK;
+        cf_kt = kt_begin;
+        cf_rs = cf_kt / tpr;
+        cf_cb = (cf_kt - cf_rs * tpr) * BK;
+        cf_r = cf_rs / p.KW;
+        cf_q = cf_rs - cf_r * p.KW;
+    }
+    auto ldb4 = [](const float* base, unsigned offb) { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + offb); };
 
     auto load_tile = [&](int kt, auto& R) {
         // ---------------- A
@@ -303,7 +332,21 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
         } else {
             const int k = kt * BK + cidx * 4;
             const bool kok = k < p.K;
-            if (AMODE == A_N || AMODE == A_NADD) {
+            if (SA) {
+                auto ubase = [](const float* q) {
+                    const uint64_t u = reinterpret_cast<uint64_t>(q);
+                    return reinterpret_cast<const float*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u));
+                };
+                const float* __restrict__ ak = ubase(A + kt * BK);
+                const float* __restrict__ xk = AMODE == A_NADD ? ubase(p.A_add + kt * BK) : nullptr;
+#pragma unroll
+                for (int i = 0; i < NLA; ++i) {
+                    R.ra[i] = ldb4(ak, sa_offb[i]);
+                    if (AMODE == A_NADD) R.rx[i] = ldb4(xk, sa_addb[i]);
+                    R.ra_ok[i] = a_ok[i];
+                }
+            } else if (AMODE == A_N || AMODE == A_NADD) {
                 // branch-free: always load from a valid address, zero by select afterwards (keeps the K loop one
                 // basic block so that the loads interleave with the MFMA stream)
                 const int kc = kok ? k : 0;
@@ -312,6 +355,29 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                     R.ra[i] = ld4(a_ptr[i] + kc);
                     if (AMODE == A_NADD) R.rx[i] = ld4(add_ptr[i] + kc);
                     R.ra_ok[i] = a_ok[i] && kok;
+                }
+            } else if (CF) {
+                // advance the scalar tap state to tile kt (branch-free: kt is the last tile asked for, or the one after it)
+                const int adv = kt != cf_kt ? 1 : 0;
+                cf_kt = kt;
+                cf_cb += adv * BK;
+                const int wrap = cf_cb >= p.Cin ? 1 : 0;
+                cf_cb = wrap ? 0 : cf_cb;
+                cf_rs += wrap;
+                cf_q += wrap;
+                const int wq = cf_q >= p.KW ? 1 : 0;
+                cf_q = wq ? 0 : cf_q;
+                cf_r += wq;
+                const int delta = (cf_r * p.W + cf_q) * p.Cin + cf_cb;
+                const bool is_x = XS && kt >= ktx;                       // second source: block-uniform
+                const float* __restrict__ abase = is_x ? Axg : A;
+                const int dk = XS ? (kt - ktx) * BK : 0;
+#pragma unroll
+                for (int i = 0; i < NLA; ++i) {
+                    const bool inb = is_x ? a_ok[i] : (((a_tapmask[i] >> cf_rs) & 1u) != 0);
+                    const int off = is_x ? a_offx[XS ? i : 0] + dk : a_off0[i] + delta;
+                    R.ra[i] = ldb4(abase, inb ? (unsigned)off * 4u : 0u);
+                    R.ra_ok[i] = inb;
                 }
             } else if (XS && kt >= ktx) {
                 // second source (block-uniform): one tap, no padding -- every valid row reads Cx contiguous channels
@@ -387,7 +453,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
             }
         }
         // ---------------- B
-        if (BMODE == B_N) {
+        if (BMODE == B_N && (CF || SA)) {
+            // uniform: this K tile's column block (read through readfirstlane so that the base lands in SGPRs and the loads
+            // take the saddr + 32-bit offset form)
+            const uint64_t bku = reinterpret_cast<uint64_t>(Bw + kt * BK);
+            const float* __restrict__ bk = reinterpret_cast<const float*>(
+                ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bku >> 32)) << 32) |
+                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bku));
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) {
+                R.rb[i] = ldb4(bk, b_offb[i]);
+                R.rb_ok[i] = b_ok[i];
+            }
+        } else if (BMODE == B_N) {
             const int k = kt * BK + cidx * 4;
             const bool kok = k < p.K;
             const int kc = kok ? k : 0;
@@ -999,7 +1077,19 @@ int launch_cfg_b(const GemmArgs& a, hipStream_t st) {
     if constexpr (HOT) {
         const bool one_a = (a.a_scale == 0.f || a.a_scale == 1.f) && !a.a_scale_dev;
         const bool one_b = BSPLIT || ((a.b_scale == 0.f || a.b_scale == 1.f) && !a.b_scale_dev);
-        const bool unmasked_ok = (a.K % BK) == 0 && one_a && one_b && a.epi == 0 && !a.amax_out && !a.finite_flag;
+        bool unmasked_ok = (a.K % BK) == 0 && one_a && one_b && a.epi == 0 && !a.amax_out && !a.finite_flag;
+        if constexpr (AMODE == A_N || AMODE == A_NADD) {
+            // the unmasked row-major flavours address both operands as uniform base + unsigned 32-bit byte offset
+            const int64_t amax_rows = a.a_rowmap ? ((int64_t)1 << 40) : a.M;        // (a row gather could point anywhere)
+            unmasked_ok = unmasked_ok && amax_rows * a.lda < ((int64_t)1 << 30) && (int64_t)a.N * a.ldb < ((int64_t)1 << 30) &&
+                          (!a.A_add || (int64_t)a.add_mod * a.ld_add < ((int64_t)1 << 30));
+        }
+        if constexpr (AMODE == A_CONV) {
+            // the unmasked convolution flavour is compiled for the uniform-tap fast path with 32-bit byte offsets only
+            const int64_t nimg = a.Ho > 0 && a.Wo > 0 ? a.M / ((int64_t)a.Ho * a.Wo) : 0;
+            unmasked_ok = unmasked_ok && (a.Cin % BK) == 0 && a.KH * a.KW <= 32 && nimg * a.img_stride < ((int64_t)1 << 30) &&
+                          (int64_t)a.H * a.W * a.Cin <= a.img_stride && (int64_t)a.N * a.ldb < ((int64_t)1 << 30);
+        }
         if constexpr (AMODE == A_CONV && BSPLIT == 1) {
             // second-source form: only built for the hot (unmasked, pre-split weights) flavour; launch_gemm has checked the rest
             if (a.Ax) return unmasked_ok ? launch_cfg_u<BM, BN, WM, WN, AMODE, BMODE, PREC, BSPLIT, 1, 1>(a, st) : -1001;
