@@ -193,9 +193,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
     // uniform base + an unsigned 32-bit byte offset per lane (global_load with an SGPR base: no 64-bit VALU adds per load), and
     // the filter tap of a K tile is tracked incrementally in scalar registers (the reciprocal-multiply decode cost ~15 VALU
     // per tile on uniform values).  Measured on the round-2 build: 108 VALU per K tile and wave in this loop against 24 MFMAs.
-    constexpr bool CF = AMODE == A_CONV && UNMASKED != 0;
+    // MEASURED SLOWER (round 3, same box, profiles/r03_slim_loader_ab.json): the convolution launches 155.6 vs 151.4 us, and the
+    // row-major flavour below (SA) 92.5 vs 81.7 us although their loops shrank from 183 to 71 and from 45 to 37 vector
+    // instructions per K tile -- the loop is not issue-bound, and loads addressed from an SGPR base behind a readfirstlane
+    // issue later than the 64-bit VGPR-addressed ones the compiler hoists to the top of the step.  Kept compiled out
+    // (ACTMI_GEMM_SLIM=1 builds it) as the record of that experiment.
+#ifndef ACTMI_GEMM_SLIM
+#define ACTMI_GEMM_SLIM 0
+#endif
+    constexpr bool CF = ACTMI_GEMM_SLIM != 0 && AMODE == A_CONV && UNMASKED != 0;
     // SA: the same addressing (uniform base + unsigned 32-bit byte offset per lane) for the row-major hot flavours
-    constexpr bool SA = (AMODE == A_N || AMODE == A_NADD) && BMODE == B_N && UNMASKED != 0;
+    constexpr bool SA = ACTMI_GEMM_SLIM != 0 && (AMODE == A_N || AMODE == A_NADD) && BMODE == B_N && UNMASKED != 0;
     const bool conv_fast = CF || (AMODE == A_CONV && (p.Cin % BK) == 0 && p.KH * p.KW <= 32 &&
                                   (int64_t)p.H * p.W * p.Cin < ((int64_t)1 << 30));
     unsigned sa_offb[SA ? NLA : 1], sa_addb[(SA && AMODE == A_NADD) ? NLA : 1];
@@ -308,11 +316,28 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
         cf_q = cf_rs - cf_r * p.KW;
     }
     auto ldb4 = [](const float* base, unsigned offb) { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + offb); };
+    // a block-uniform pointer, read through readfirstlane so that it provably lives in SGPRs (loads then take the saddr form)
+    auto ubase = [](const float* q) {
+        const uint64_t u = reinterpret_cast<uint64_t>(q);
+        return reinterpret_cast<const float*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                              (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u));
+    };
+    // transposed-storage operands ([contraction][out]): a tile that lies inside the matrix, on a K tile that lies inside the
+    // contraction, is four plain 16-byte loads per thread from uniform row bases -- the general form below (per-element
+    // bounds, scalar tails: ~200 branches in the compiled loop) only runs on the matrix edges
+    const bool at_interior = AMODE == A_T && m0 + BM <= p.M;
+    const bool bt_interior = BMODE == B_T && n0 + BN <= p.N && p.B_add == nullptr;
+    const unsigned at_offb = AMODE == A_T ? ((unsigned)(a_kg * 4) * (unsigned)p.lda + (unsigned)(m0 + a_og * 4)) * 4u : 0u;
+    const unsigned bt_offb = BMODE == B_T ? ((unsigned)(b_kg * 4) * (unsigned)p.ldb + (unsigned)(n0 + b_og * 4)) * 4u : 0u;
 
     auto load_tile = [&](int kt, auto& R) {
         // ---------------- A
         if (AMODE == A_T) {
-            if (a_kg < NPL) {
+            if (a_kg < NPL && at_interior && (kt + 1) * BK <= p.K) {
+                const float* __restrict__ rb = ubase(A + (int64_t)kt * BK * p.lda);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) R.ra[j] = ldb4(rb + (int64_t)j * p.lda, at_offb);
+            } else if (a_kg < NPL) {
                 const int o = m0 + a_og * 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -333,11 +358,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
             const int k = kt * BK + cidx * 4;
             const bool kok = k < p.K;
             if (SA) {
-                auto ubase = [](const float* q) {
-                    const uint64_t u = reinterpret_cast<uint64_t>(q);
-                    return reinterpret_cast<const float*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
-                                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u));
-                };
                 const float* __restrict__ ak = ubase(A + kt * BK);
                 const float* __restrict__ xk = AMODE == A_NADD ? ubase(p.A_add + kt * BK) : nullptr;
 #pragma unroll
@@ -475,7 +495,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                 R.rb_ok[i] = b_ok[i] && kok;
             }
         } else if (BMODE == B_T) {
-            if (b_kg < NPL) {
+            if (b_kg < NPL && bt_interior && (kt + 1) * BK <= p.K) {
+                const float* __restrict__ rb = ubase(Bw + (int64_t)kt * BK * p.ldb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) R.rb[j] = ldb4(rb + (int64_t)j * p.ldb, bt_offb);
+            } else if (b_kg < NPL) {
                 const int o = n0 + b_og * 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1078,13 +1102,13 @@ int launch_cfg_b(const GemmArgs& a, hipStream_t st) {
         const bool one_a = (a.a_scale == 0.f || a.a_scale == 1.f) && !a.a_scale_dev;
         const bool one_b = BSPLIT || ((a.b_scale == 0.f || a.b_scale == 1.f) && !a.b_scale_dev);
         bool unmasked_ok = (a.K % BK) == 0 && one_a && one_b && a.epi == 0 && !a.amax_out && !a.finite_flag;
-        if constexpr (AMODE == A_N || AMODE == A_NADD) {
+        if constexpr (ACTMI_GEMM_SLIM != 0 && (AMODE == A_N || AMODE == A_NADD)) {
             // the unmasked row-major flavours address both operands as uniform base + unsigned 32-bit byte offset
             const int64_t amax_rows = a.a_rowmap ? ((int64_t)1 << 40) : a.M;        // (a row gather could point anywhere)
             unmasked_ok = unmasked_ok && amax_rows * a.lda < ((int64_t)1 << 30) && (int64_t)a.N * a.ldb < ((int64_t)1 << 30) &&
                           (!a.A_add || (int64_t)a.add_mod * a.ld_add < ((int64_t)1 << 30));
         }
-        if constexpr (AMODE == A_CONV) {
+        if constexpr (ACTMI_GEMM_SLIM != 0 && AMODE == A_CONV) {
             // the unmasked convolution flavour is compiled for the uniform-tap fast path with 32-bit byte offsets only
             const int64_t nimg = a.Ho > 0 && a.Wo > 0 ? a.M / ((int64_t)a.Ho * a.Wo) : 0;
             unmasked_ok = unmasked_ok && (a.Cin % BK) == 0 && a.KH * a.KW <= 32 && nimg * a.img_stride < ((int64_t)1 << 30) &&
