@@ -495,7 +495,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                 R.rb_ok[i] = b_ok[i] && kok;
             }
         } else if (BMODE == B_T) {
-            if (b_kg < NPL && bt_interior && (kt + 1) * BK <= p.K) {
+            // (the same interior fast path measured 5 % SLOWER on this operand -- A_N x B_T 651 vs 617 us at the training shapes --
+            // while the A_T one gains 11 %: off)
+            if (false && b_kg < NPL && bt_interior && (kt + 1) * BK <= p.K) {
                 const float* __restrict__ rb = ubase(Bw + (int64_t)kt * BK * p.ldb);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) R.rb[j] = ldb4(rb + (int64_t)j * p.ldb, bt_offb);
@@ -532,18 +534,23 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                 int pho = (int)((float)prem * wg_inv_wo);
                 int pwo = prem - pho * p.Wo;
                 if (pwo < 0) { --pho; pwo += p.Wo; } else if (pwo >= p.Wo) { ++pho; pwo -= p.Wo; }
+                // branch-free: a load under a divergent branch is waited for on the spot (the four gathers of a step then run
+                // one after the other, each a full memory round trip); here every lane always loads from a valid address (the
+                // image's first element when its tap is padding or its pixel beyond the contraction) and the staging zeroes it
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int mm = mm0 + j;
-                    f32x4 v = zero4;
                     const int b = pb, ho = pho, wo = pwo;
-                    if (++pwo == p.Wo) { pwo = 0; if (++pho == p.Ho) { pho = 0; ++pb; } }
-                    if (ook && mm < p.K) {
-                        const int hi = ho * p.stride - p.pad + wg_r, wi = wo * p.stride - p.pad + wg_s;
-                        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                            v = ld4(Bw + (int64_t)b * p.img_stride + ((int64_t)hi * p.W + wi) * p.Cin + wg_c);
-                    }
-                    R.rb[j] = v;
+                    const bool wrapw = pwo + 1 == p.Wo;
+                    const bool wraph = wrapw && pho + 1 == p.Ho;
+                    pwo = wrapw ? 0 : pwo + 1;
+                    pho = wraph ? 0 : (wrapw ? pho + 1 : pho);
+                    pb += wraph ? 1 : 0;
+                    const int hi = ho * p.stride - p.pad + wg_r, wi = wo * p.stride - p.pad + wg_s;
+                    const bool ok = ook && mm < p.K && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                    const int64_t off = ok ? (int64_t)b * p.img_stride + (int64_t)((hi * p.W + wi) * p.Cin + wg_c) : 0;
+                    R.rb[j] = ld4(Bw + off);
+                    R.rb_ok[j] = ok;
                 }
             }
         }
@@ -617,7 +624,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
             if (b_kg < NPL) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 v = f32x4{R.rb[0][i], R.rb[1][i], R.rb[2][i], R.rb[3][i]} * pre_b;
+                    f32x4 v = f32x4{R.rb[0][i], R.rb[1][i], R.rb[2][i], R.rb[3][i]} * pre_b;
+                    if (BMODE == B_WGRAD) v = f32x4{R.rb_ok[0] ? v[0] : 0.f, R.rb_ok[1] ? v[1] : 0.f, R.rb_ok[2] ? v[2] : 0.f, R.rb_ok[3] ? v[3] : 0.f};
                     uint2 hi, lo;
                     const int row = swz_row(b_og * 4 + i);
                     if (PREC == PREC_BF16) sb8[(((b_kg >> 1) * 2 + 0) * PSB + row) * 2 + (b_kg & 1)] = pack_bf16x4(v);
@@ -657,7 +665,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
             if (b_kg < NPL) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 v = {R.rb[0][i], R.rb[1][i], R.rb[2][i], R.rb[3][i]};
+                    f32x4 v = {R.rb[0][i], R.rb[1][i], R.rb[2][i], R.rb[3][i]};
+                    if (BMODE == B_WGRAD) v = f32x4{R.rb_ok[0] ? v[0] : 0.f, R.rb_ok[1] ? v[1] : 0.f, R.rb_ok[2] ? v[2] : 0.f, R.rb_ok[3] ? v[3] : 0.f};
                     sb[b_kg * PSB + swz_row(b_og * 4 + i)] = v;
                 }
             }
