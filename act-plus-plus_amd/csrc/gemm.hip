@@ -495,9 +495,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                 R.rb_ok[i] = b_ok[i] && kok;
             }
         } else if (BMODE == B_T) {
-            // (the same interior fast path measured 5 % SLOWER on this operand -- A_N x B_T 651 vs 617 us at the training shapes --
-            // while the A_T one gains 11 %: off)
-            if (false && b_kg < NPL && bt_interior && (kt + 1) * BK <= p.K) {
+            // (measured at the training shapes: with a transposed A beside it this interior path takes the A_T x B_T launches from
+            // 345 to 308 us; beside a row-major A the same path is 5 % SLOWER -- A_N x B_T 651 vs 617 us -- so only then)
+            if (AMODE == A_T && b_kg < NPL && bt_interior && (kt + 1) * BK <= p.K) {
                 const float* __restrict__ rb = ubase(Bw + (int64_t)kt * BK * p.ldb);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) R.rb[j] = ldb4(rb + (int64_t)j * p.ldb, bt_offb);
