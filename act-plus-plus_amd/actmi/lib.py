@@ -51,7 +51,7 @@ class GemmDesc(C.Structure):
         ("finite_flag", C.c_void_p), ("finite_bit", C.c_uint32),
         ("Ax", C.c_void_p), ("kx_begin", C.c_int32), ("Hx", C.c_int32), ("Wx", C.c_int32), ("Cx", C.c_int32),
         ("stride_x", C.c_int32), ("gAx", C.c_int64),
-        ("A_alt", C.c_void_p), ("alt_ncols", C.c_int32),
+        ("A_alt", C.c_void_p), ("alt_ncols", C.c_int32), ("k_tap_inner", C.c_int32),
     ]
 
 
@@ -128,6 +128,7 @@ def load():
         "actmi_ensemble_step": ([vp, vp, vp, f64, vp, vp, i32, i32, i32, vp], i32),
         "actmi_op_gemm": ([C.POINTER(GemmDesc), vp], i32),
         "actmi_op_split16": ([vp, vp, C.c_int64, C.c_float, vp], i32),
+        "actmi_op_permute_conv_k": ([vp, vp, C.c_int64, i32, i32, i32, vp], i32),
         "actmi_op_sample_onehot": ([vp, i32, i32, C.c_float, C.c_uint64, vp, vp, vp], i32),
         "actmi_op_pow2_scale": ([vp, C.c_int64, i32, i32, vp, vp], i32),
         "actmi_op_split16v2": ([vp, vp, C.c_int64, C.c_float, vp], i32),

@@ -23,6 +23,18 @@ def split16(w, scale=1.0):
     return out
 
 
+def permute_conv_k(w_rows, taps, cin):
+    """[rows, ld] convolution weight rows, the first taps*cin columns re-ordered (tap, c) -> (c / 32, tap, c % 32): the K order
+    the engine's split images use (actmi_gemm_desc.k_tap_inner)."""
+    lib = L.load()
+    w_rows = w_rows.contiguous()
+    out = torch.empty_like(w_rows)
+    rows, ld = w_rows.numel() // w_rows.shape[-1], w_rows.shape[-1]
+    L.check(lib.actmi_op_permute_conv_k(_p(w_rows), _p(out), rows, int(taps), int(cin), int(ld), L.current_stream_ptr()), None,
+            "op_permute_conv_k")
+    return out
+
+
 def pow2_scale(x):
     """[scale, scratch]: scale = the power of two that brings max|x| into [2^13, 2^14) (device-side, no host sync);
     pass the tensor as gemm(..., a_scale_dev=) / b_scale_dev= for operands far from the fp16 range."""
@@ -171,7 +183,7 @@ def gemm16(A16, W16, alpha=1.0, bias=None, scale=None, res=None, res_fmt="s16", 
     return out
 
 
-def conv2d_with_second_source(y1, x, wf_split, w_scale, bias, stride_x=2, relu=True, splitk=0):
+def conv2d_with_second_source(y1, x, wf_split, w_scale, bias, stride_x=2, relu=True, splitk=0, k_tap_inner=False):
     """A ResNet block's conv2 with the block's 1x1 / stride-2 downsample branch in the same contraction (gemm.hip second
     source): y1 [G,B,H,W,C] is convolved 3x3 / s1 / p1, x [G,B,Hx,Wx,Cx] joins at stride_x as extra columns of the contraction.
     wf_split: split16 image (built with w_scale) of [G][Cout][9*C + Cx]; bias [G,Cout].  f16x3 only.  Returns [G,B,H,W,Cout]."""
@@ -194,6 +206,7 @@ def conv2d_with_second_source(y1, x, wf_split, w_scale, bias, stride_x=2, relu=T
         d.M, d.N, d.K, d.groups = M, Cout, Kf, G
         d.gA, d.gB, d.gSB, d.gC = B * H * W * Cc, Cout * Kf, Cout, gC
         d.prec, d.b_split, d.b_scale = PREC["f16x3"], 1, float(w_scale)
+        d.k_tap_inner = 1 if k_tap_inner else 0
         return d
     out = torch.empty((G, B, H, W, Cout), dtype=torch.float32, device=y1.device)
     if splitk and splitk > 1:
@@ -212,8 +225,10 @@ def conv2d_with_second_source(y1, x, wf_split, w_scale, bias, stride_x=2, relu=T
     return out
 
 
-def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1, pad=1, prec=None, w_split=False, b_scale=0.0):
-    """x [G,B,H,W,Cin] camera-major NHWC; w_ohwi [G,Cout,KH,KW,Cin]; scale/bias [G,Cout]; returns [G,B,Ho,Wo,Cout]."""
+def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1, pad=1, prec=None, w_split=False, b_scale=0.0,
+                k_tap_inner=False):
+    """x [G,B,H,W,Cin] camera-major NHWC; w_ohwi [G,Cout,KH,KW,Cin]; scale/bias [G,Cout]; returns [G,B,Ho,Wo,Cout].
+    k_tap_inner: the rows of w_ohwi were re-ordered by permute_conv_k (channel blocks outer, taps inner)."""
     lib = L.load()
     G, B, H, W, Cin = x.shape
     _, Cout, KH, KW, _ = w_ohwi.shape
@@ -235,6 +250,7 @@ def conv2d_nhwc(x, w_ohwi, scale=None, bias=None, res=None, relu=False, stride=1
     d.gC = d.gRes = B * Ho * Wo * Cout
     # f16x3: w_split = scale of a pre-split weight image; b_scale = power-of-two scale applied to plain fp32 weights on the fly
     d.prec, d.b_split, d.b_scale = PREC[prec], 1 if w_split else 0, float(w_split) if w_split else float(b_scale)
+    d.k_tap_inner = 1 if k_tap_inner else 0
     L.check(lib.actmi_op_gemm(C.byref(d), L.current_stream_ptr()), None, "op_gemm(conv)")
     return out
 

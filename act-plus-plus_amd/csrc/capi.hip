@@ -226,6 +226,13 @@ int actmi_op_split16(const float* src, float* dst, int64_t nfloats, float scale,
     return rc == 0 ? 0 : ACTMI_E_INVALID;
 }
 
+int actmi_op_permute_conv_k(const float* src, float* dst, int64_t rows, int taps, int cin, int ld, void* stream) {
+    g_op_error.clear();
+    const int rc = launch_permute_conv_k(src, dst, rows, taps, cin, ld, S(stream));
+    if (rc != 0) g_op_error = "permute_conv_k: cin must be a multiple of 32, ld >= taps*cin, src != dst";
+    return rc == 0 ? 0 : (rc == -2 ? ACTMI_E_INVALID : ACTMI_E_LAUNCH);
+}
+
 int actmi_op_split16v2(const float* src, void* dst, int64_t nfloats, float scale, void* stream) {
     g_op_error.clear();
     const int rc = launch_split16v2(src, dst, nfloats, scale, S(stream));

@@ -155,6 +155,7 @@ int launch_ensemble(float* ring, int* tcount, const float* chunk, double k, doub
 int launch_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale, float* bias, int n,
                    hipStream_t st);
 int launch_build_rowmap(int* map, int B, int C, int fh, int fw, int N, hipStream_t st);
+int launch_permute_conv_k(const float* src, float* dst, int64_t rows, int taps, int cin, int ld, hipStream_t st);
 // [s2 * w2 | sd * wd] per output row + summed bias: the fused weights of a block's conv2 + downsample (misc.hip)
 int launch_fold_cat_w(const float* w2, const float* s2, const float* b2, const float* wd, const float* sd, const float* bd,
                       float* out, float* bias, int G, int N, int K2, int Kd, hipStream_t st);

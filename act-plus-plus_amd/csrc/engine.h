@@ -41,6 +41,9 @@ struct ConvLayer {
     // calibration forward of actmi_finalize found the input far from the fp16 range (FrozenBN statistics of a trained
     // checkpoint can leave a map at 1e-5 or 1e4); undone through the epilogue's alpha
     float a_scale = 1.f;
+    // the split images (w16, wf16) store their K index channel-block-major, taps inner (actmi_gemm_desc.k_tap_inner): every 3x3
+    // convolution that runs on the implicit-GEMM kernel with Cin % 32 == 0; the direct kernels (layer1) keep (r, s, c)
+    bool k_tap_inner = false;
 };
 
 struct MhaW { float *in_w, *in_b, *out_w, *out_b; };

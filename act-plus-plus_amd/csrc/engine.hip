@@ -169,10 +169,10 @@ int ctx_gemm(actmi_ctx* ctx, GemmArgs a, hipStream_t st, int ws_half, LnFuse* ln
         } else {
             for (const ConvLayer& cl : ctx->convs) {
                 if (a.Bw >= cl.w && a.Bw < cl.w + (int64_t)ctx->cfg.num_cams * cl.cout * cl.K) {     // (a camera's slice of it)
-                    a.Bw = cl.w16 + (a.Bw - cl.w); a.b_split = 1; a.b_scale = cl.w16_scale; break;
+                    a.Bw = cl.w16 + (a.Bw - cl.w); a.b_split = 1; a.b_scale = cl.w16_scale; a.k_tap_inner = cl.k_tap_inner ? 1 : 0; break;
                 }
                 if (cl.wf && a.Bw >= cl.wf && a.Bw < cl.wf + (int64_t)ctx->cfg.num_cams * cl.cout * (cl.K + cl.Kx)) {
-                    a.Bw = cl.wf16 + (a.Bw - cl.wf); a.b_split = 1; a.b_scale = cl.wf16_scale; break;
+                    a.Bw = cl.wf16 + (a.Bw - cl.wf); a.b_split = 1; a.b_scale = cl.wf16_scale; a.k_tap_inner = cl.k_tap_inner ? 1 : 0; break;
                 }
             }
         }
@@ -633,8 +633,20 @@ int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st, bool after_step) {
         // finalize raises ACTMI_FLAG_WEIGHT instead of silently becoming inf
         CHK(launch_split16_map(ctx->pbase, ctx->p16base, ctx->ptotal, ctx->pseg64, ctx->pscale_dev, ctx->flags, st));
         CHK(launch_conv1_wimg(ctx->conv1_w, ctx->conv1_wimg, C, w0, st, ctx->conv1_wscale));
-        for (const ConvLayer& cl : ctx->convs)
-            CHK(launch_split16(cl.w, cl.w16, (int64_t)C * cl.cout * cl.K, cl.w16_scale, st, ctx->flags));
+        static const bool tap_inner_on = !(getenv("ACTMI_K_TAP_INNER") && getenv("ACTMI_K_TAP_INNER")[0] == '0');
+        for (ConvLayer& cl : ctx->convs) {
+            // K order of the image: channel blocks outer, taps inner, for the convolutions of the implicit-GEMM kernel (L2 reuse of
+            // the input patch); the direct kernels of layer1 (and the opt-in conv3g) read (r, s, c)
+            const bool direct = cl.k == 3 && cl.stride == 1 && cl.pad == 1 && ((cl.cin == 64 && cl.cout == 64) || ctx->conv_direct);
+            cl.k_tap_inner = tap_inner_on && cl.k == 3 && (cl.cin % 32) == 0 && !direct &&
+                             (int64_t)C * cl.cout * (cl.K + cl.Kx) <= ctx->splitk_ws_floats;
+            if (cl.k_tap_inner) {
+                CHK(launch_permute_conv_k(cl.w, ctx->splitk_ws, (int64_t)C * cl.cout, cl.k * cl.k, cl.cin, cl.K, st));
+                CHK(launch_split16(ctx->splitk_ws, cl.w16, (int64_t)C * cl.cout * cl.K, cl.w16_scale, st, ctx->flags));
+            } else {
+                CHK(launch_split16(cl.w, cl.w16, (int64_t)C * cl.cout * cl.K, cl.w16_scale, st, ctx->flags));
+            }
+        }
         // blocks with a downsample branch: [bn2.scale * conv2.w | bn_ds.scale * ds.w] and the summed bias (FrozenBN statistics
         // are buffers: only the weights change under training, so the fold is redone with them)
         for (const ConvLayer& cl : ctx->convs)
@@ -643,7 +655,12 @@ int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st, bool after_step) {
                 CHK(launch_fold_cat_w(cl.w, cl.scale, cl.bias, ds.w, ds.scale, ds.bias, cl.wf, cl.bias_f, C, cl.cout, cl.K, cl.Kx, st));
                 // (at finalize the scale is measured right after this and the image split again: no overflow report from the
                 // provisional one)
-                CHK(launch_split16(cl.wf, cl.wf16, (int64_t)C * cl.cout * (cl.K + cl.Kx), cl.wf16_scale, st, after_step ? ctx->flags : nullptr));
+                const float* src = cl.wf;
+                if (cl.k_tap_inner) {
+                    CHK(launch_permute_conv_k(cl.wf, ctx->splitk_ws, (int64_t)C * cl.cout, cl.k * cl.k, cl.cin, cl.K + cl.Kx, st));
+                    src = ctx->splitk_ws;
+                }
+                CHK(launch_split16(src, cl.wf16, (int64_t)C * cl.cout * (cl.K + cl.Kx), cl.wf16_scale, st, after_step ? ctx->flags : nullptr));
             }
     }
     // learned rows of the token position table (transformer.py:91-92)
@@ -724,7 +741,13 @@ int engine_finalize(actmi_ctx* ctx, hipStream_t st) {
                 float v = sc[2 * i];
                 if (!(v > 0.f) || !(v <= 3.0e38f)) { ctx->err = "fused weights of " + fl[i]->name + " are not finite"; return ACTMI_E_INVALID; }
                 fl[i]->wf16_scale = v < 4096.f ? v : 4096.f;
-                CHK(launch_split16(fl[i]->wf, fl[i]->wf16, (int64_t)ctx->cfg.num_cams * fl[i]->cout * (fl[i]->K + fl[i]->Kx),
+                const float* src = fl[i]->wf;
+                if (fl[i]->k_tap_inner) {
+                    CHK(launch_permute_conv_k(fl[i]->wf, ctx->splitk_ws, (int64_t)ctx->cfg.num_cams * fl[i]->cout, fl[i]->k * fl[i]->k, fl[i]->cin,
+                                              fl[i]->K + fl[i]->Kx, st));
+                    src = ctx->splitk_ws;
+                }
+                CHK(launch_split16(src, fl[i]->wf16, (int64_t)ctx->cfg.num_cams * fl[i]->cout * (fl[i]->K + fl[i]->Kx),
                                    fl[i]->wf16_scale, st, ctx->flags));
             }
         }

@@ -214,6 +214,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
     const int ktx = XS ? p.kx_begin / BK : 0x7fffffff;      // first K tile of the second source
     const float conv_inv_tpr = (AMODE == A_CONV && conv_fast) ? 1.0f / (float)(p.Cin / BK) : 0.f;
     const float conv_inv_kw = (AMODE == A_CONV || AMODE == A_DGRAD) ? 1.0f / (float)p.KW : 0.f;
+    const float conv_inv_ntap = (AMODE == A_CONV) ? 1.0f / (float)(p.KH * p.KW) : 0.f;
     const int dg_cq = (AMODE == A_DGRAD) ? p.K / (p.KH * p.KW) : BK;
     const bool dgrad_fast = AMODE == A_DGRAD && (dg_cq % BK) == 0 && (p.stride == 1 || p.stride == 2) &&
                             (int64_t)p.Ho * p.Wo * dg_cq < ((int64_t)1 << 30);
@@ -409,9 +410,21 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (PREC && BM * BN <= 128
                 }
             } else if (AMODE == A_CONV && conv_fast) {
                 // uniform tap of this K tile (small exact integer divisions via reciprocal multiply: kt < 2^20)
+                // K order of the weight rows: (r, s, c) as the reference stores them, or -- k_tap_inner, the engine's split images of
+                // the 3x3 convolutions -- (channel block of 32, r, s, channel): then the nine taps of a channel block follow each
+                // other, a workgroup cycles through a quarter-to-sixteenth of its input patch at a time and the ~64 tiles an XCD
+                // runs together keep their patches in its 4 MB L2 instead of re-fetching every tap through the fabric
                 const int tpr = p.Cin / BK;
-                const int rs = (int)(((float)kt + 0.5f) * conv_inv_tpr);
-                const int cb = (kt - rs * tpr) * BK;
+                const int ntap = p.KH * p.KW;
+                int rs, cb;
+                if (p.k_tap_inner) {
+                    const int cbi = (int)(((float)kt + 0.5f) * conv_inv_ntap);
+                    rs = kt - cbi * ntap;
+                    cb = cbi * BK;
+                } else {
+                    rs = (int)(((float)kt + 0.5f) * conv_inv_tpr);
+                    cb = (kt - rs * tpr) * BK;
+                }
                 const int r = (int)(((float)rs + 0.5f) * conv_inv_kw);
                 const int q = rs - r * p.KW;
                 const int delta = (r * p.W + q) * p.Cin + cb;
@@ -1271,6 +1284,8 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t st, std::string* err) {
             } else if (a.K != a.KH * a.KW * a.Cin) return fail("K != KH*KW*Cin");
             if (a.A_add || a.a_rowmap) return fail("addend not supported in conv mode");
             if (a.M % (a.Ho * a.Wo)) return fail("M must be images*Ho*Wo");
+            if (a.k_tap_inner && ((a.Cin % BK) || a.KH * a.KW > 32 || (int64_t)a.H * a.W * a.Cin >= ((int64_t)1 << 30)))
+                return fail("k_tap_inner needs Cin % 32 == 0 (the uniform-tap loader)");
             amode = A_CONV;
         } else if (a.mode == 2) {
             if (a.K % (a.KH * a.KW) || ((a.K / (a.KH * a.KW)) & 3)) return fail("dgrad: K must be KH*KW*Cout, Cout % 4 == 0");

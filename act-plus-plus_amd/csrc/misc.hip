@@ -585,6 +585,29 @@ int launch_fold_cat_w(const float* w2, const float* s2, const float* b2, const f
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// K order of a convolution weight matrix for L2 reuse of the input patch (gemm.hip, k_tap_inner): (tap, c) -> (c / 32, tap, c % 32)
+__global__ void permute_conv_k_kernel(const float* __restrict__ src, float* __restrict__ dst, int taps, int cin, int ld, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int k = (int)(idx % ld);
+    const int64_t row = idx / ld;
+    int ks = k;                                   // source column of destination column k
+    if (k < taps * cin) {
+        const int cb = k / (taps * 32), rem = k - cb * taps * 32;
+        const int tap = rem / 32, ci = rem - tap * 32;
+        ks = tap * cin + cb * 32 + ci;
+    }
+    dst[idx] = src[row * ld + ks];
+}
+
+int launch_permute_conv_k(const float* src, float* dst, int64_t rows, int taps, int cin, int ld, hipStream_t st) {
+    if (rows <= 0) return 0;
+    if ((cin & 31) || taps < 1 || ld < taps * cin || src == dst) return -2;
+    const int64_t total = rows * ld;
+    hipLaunchKernelGGL(permute_conv_k_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, dst, taps, cin, ld, total);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 int launch_build_rowmap(int* map, int B, int C, int fh, int fw, int N, hipStream_t st) {
     const int total = C * B * fh * fw;
     hipLaunchKernelGGL(build_rowmap_kernel, dim3((total + 255) / 256), dim3(256), 0, st, map, B, C, fh, fw, N);

@@ -175,6 +175,11 @@ typedef struct actmi_gemm_desc {
      * (transformer.py:216-217) when x + pos already exists as a matrix */
     const float* A_alt;
     int32_t alt_ncols;
+    /* mode 1, Cin % 32 == 0: the K index of the Bw rows is ((c / 32) * KH*KW + r*KW + s) * 32 + c % 32 (channel blocks outer,
+     * taps inner) instead of (r*KW + s) * Cin + c -- the order of the engine's split images of the 3x3 convolutions, chosen for
+     * L2 reuse of the input patch (actmi_op_permute_conv_k builds it from the reference order).  With a second source (Ax) the
+     * extra Cx columns still follow the KH*KW*Cin permuted ones. */
+    int32_t k_tap_inner;
 } actmi_gemm_desc;
 
 /* GEMM / implicit-GEMM convolution on PRE-SPLIT operands (the inference path's form of actmi_gemm_desc with prec f16x3;
@@ -320,6 +325,9 @@ int actmi_op_gemm(const actmi_gemm_desc* d, void* stream);
  * alias).  scale must be a power of two with |src| * scale < 65504; 256 suits network weights: pieces of values
  * around 1e-2 then stay normal fp16 numbers (full 22-bit split) instead of subnormals. */
 int actmi_op_split16(const float* src, float* dst, int64_t nfloats, float scale, void* stream);
+/* rows [rows][ld] of a convolution weight matrix: the first taps*cin columns re-ordered from (tap, c) to (c / 32, tap, c % 32)
+ * (actmi_gemm_desc.k_tap_inner), any further columns (ld > taps*cin: a second source's) copied as they are; cin % 32 == 0 */
+int actmi_op_permute_conv_k(const float* src, float* dst, int64_t rows, int taps, int cin, int ld, void* stream);
 /* s16 form of a row-major f32 tensor (actmi_gemm16_desc): dst = split of (src * scale), nfloats % 8 == 0, device pointers
  * that may not alias; scale a power of two with |src| * scale < 65504.  actmi_op_unsplit16v2 is the inverse
  * (dst = (hi + lo) / scale: exact to the 22-23 significand bits the split keeps). */

@@ -456,6 +456,29 @@ def test_conv2_with_downsample_as_second_source(G, B, H, W, Cc, Cx, Cout, splitk
                     (wd * sd.view(G, Cout, 1, 1, 1)).reshape(G, Cout, Cx)], dim=2).contiguous()
     scale = 256.0
     wf16 = ops.split16(wf.to(d), scale)
-    got = ops.conv2d_with_second_source(y1.permute(0, 1, 3, 4, 2).contiguous().to(d), x.permute(0, 1, 3, 4, 2).contiguous().to(d),
-                                        wf16, scale, (b2 + bd).to(d), splitk=splitk)
+    y1n, xn = y1.permute(0, 1, 3, 4, 2).contiguous().to(d), x.permute(0, 1, 3, 4, 2).contiguous().to(d)
+    got = ops.conv2d_with_second_source(y1n, xn, wf16, scale, (b2 + bd).to(d), splitk=splitk)
     assert rel_err(got.permute(0, 1, 4, 2, 3), exp) < 3e-6
+    # the engine's K order (channel blocks outer, taps inner; the second source's columns stay behind them): same result
+    wfp16 = ops.split16(ops.permute_conv_k(wf.to(d), 9, Cc), scale)
+    got2 = ops.conv2d_with_second_source(y1n, xn, wfp16, scale, (b2 + bd).to(d), splitk=splitk, k_tap_inner=True)
+    assert rel_err(got2.permute(0, 1, 4, 2, 3), exp) < 3e-6
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("G,B,H,W,Cin,Cout,stride", [(2, 2, 15, 20, 64, 64, 1), (1, 2, 30, 40, 128, 96, 2), (1, 1, 9, 11, 32, 256, 1)])
+def test_conv_k_order_taps_inner(G, B, H, W, Cin, Cout, stride, prec):
+    """actmi_gemm_desc.k_tap_inner: weight rows in (channel block, tap, channel) order give the convolution of the (tap, channel)
+    rows (only the summation order inside the fp32 accumulation differs); the permutation itself is checked element by element."""
+    g = torch.Generator().manual_seed(Cin + H)
+    d = dev()
+    x = torch.randn(G, B, H, W, Cin, generator=g).to(d)
+    w = (torch.randn(G, Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5).to(d)
+    bias = torch.randn(G, Cout, generator=g).to(d)
+    ref = ops.conv2d_nhwc(x, w, bias=bias, relu=True, stride=stride, pad=1, prec=prec, b_scale=256.0 if prec == "f16x3" else 0.0)
+    wp = ops.permute_conv_k(w.reshape(G * Cout, 9 * Cin), 9, Cin)
+    exp_perm = w.reshape(G * Cout, 9, Cin // 32, 32).permute(0, 2, 1, 3).reshape(G * Cout, 9 * Cin)
+    assert torch.equal(wp, exp_perm)
+    got = ops.conv2d_nhwc(x, wp.reshape(G, Cout, 3, 3, Cin), bias=bias, relu=True, stride=stride, pad=1, prec=prec,
+                          b_scale=256.0 if prec == "f16x3" else 0.0, k_tap_inner=True)
+    assert rel_err(got, ref) < 2e-6

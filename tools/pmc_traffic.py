@@ -25,11 +25,14 @@ def short_name(n):
 
 
 def collect(path, counter):
+    """per kernel AND per (kernel, workgroups): the grid size tells the launch shapes of one kernel apart (layer2 / 3 / 4)"""
     tot, cnt = defaultdict(float), defaultdict(int)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
             k = short_name(r["Kernel_Name"])
             tot[k] += float(r["Counter_Value"]); cnt[k] += 1
+            wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
+            tot[(k, wgs)] += float(r["Counter_Value"]); cnt[(k, wgs)] += 1
     return tot, cnt
 
 
@@ -37,10 +40,16 @@ ft, fc = collect(sys.argv[1], "FETCH_SIZE")
 wt, wc = collect(sys.argv[2], "WRITE_SIZE")
 out = {"note": sys.argv[4] if len(sys.argv) > 4 else "", "commit": sys.argv[5] if len(sys.argv) > 5 else None,
        "kernel_source_sha16": kernel_source_sha16(), "kernels": {}}
+out["per_shape"] = []
 for k in ft:
     f = ft[k] / max(fc[k], 1) * 1024 * 2
     w = wt.get(k, 0.0) / max(wc.get(k, 0), 1) * 1024
-    out["kernels"][k] = {"launches": fc[k], "fetch_bytes_per_launch": f, "write_bytes_per_launch": w,
-                         "traffic_bytes_per_launch": f + w}
+    rec = {"launches": fc[k], "fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "traffic_bytes_per_launch": f + w}
+    if isinstance(k, tuple):
+        if k[0].startswith("gemm_") or k[0].startswith("conv") or k[0].startswith("attn"):
+            out["per_shape"].append(dict(rec, kernel=k[0], workgroups=k[1]))
+    else:
+        out["kernels"][k] = rec
+out["per_shape"].sort(key=lambda r: -r["traffic_bytes_per_launch"] * r["launches"])
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print("kernels:", len(out["kernels"]))
