@@ -26,6 +26,23 @@ constexpr bool ATTN_NOPF = true;
 constexpr int KT = 64;   // keys per LDS tile
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
+// XCD-aware block order: the hardware deals consecutive block ids round-robin over the 8 XCDs (each with its own 4 MB L2), so
+// the query blocks of one (batch, head) -- which all stream the same K / V -- used to land on all eight and each L2 fetched
+// that K / V again (201 MB of fabric reads per encoder launch against 79 MB of operands, PMC round 3).  The bijective remap
+// gives every XCD a contiguous run of (batch, head, query block) triples, as gemm.hip does for its tiles.
+__device__ __forceinline__ void attn_block_coords(int& bx, int& by, int& bz) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int total = gx * gy * (int)gridDim.z;
+    const int lin = ((int)blockIdx.z * gy + (int)blockIdx.y) * gx + (int)blockIdx.x;
+    const int xcd = lin & 7, q = total >> 3, r = total & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int flat = base + (lin >> 3);
+    bx = flat % gx;
+    const int rest = flat / gx;
+    by = rest % gy;
+    bz = rest / gy;
+}
+
 template <int HD>
 __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p, int nsplit, int chunk) {
     constexpr int HH = HD / 2;            // k-steps of the QK^T product per lane half
@@ -37,9 +54,10 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p, int nsplit, i
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int split = blockIdx.x % nsplit;
-    const int q = (blockIdx.x / nsplit) * 128 + wave * 32 + li;
+    int bx, h, b;
+    attn_block_coords(bx, h, b);
+    const int split = bx % nsplit;
+    const int q = (bx / nsplit) * 128 + wave * 32 + li;
     const int k_begin = split * chunk;
     const int k_end = (k_begin + chunk < p.Nk) ? k_begin + chunk : p.Nk;      // this block's key range
     const bool qok = q < p.Nq;
@@ -234,9 +252,10 @@ __global__ __launch_bounds__(256, 3) void attn_f16x3_kernel(AttnArgs p, int nspl
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int split = blockIdx.x % nsplit;
-    const int q = (blockIdx.x / nsplit) * 128 + wave * 32 + li;
+    int bx, h, b;
+    attn_block_coords(bx, h, b);
+    const int split = bx % nsplit;
+    const int q = (bx / nsplit) * 128 + wave * 32 + li;
     const int k_begin = split * chunk;
     const int k_end = (k_begin + chunk < p.Nk) ? k_begin + chunk : p.Nk;
     const bool qok = q < p.Nq;

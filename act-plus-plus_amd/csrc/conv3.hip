@@ -41,7 +41,17 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_f16x3_kernel(Conv3Args p, in
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
 
-    int tile = blockIdx.x;
+    // XCD-aware tile order (as in gemm.hip / attn.hip): consecutive block ids go round-robin over the 8 XCDs, so neighbouring
+    // tiles -- which share their halo rows and columns -- used to sit in eight different L2s and every halo pixel crossed the
+    // fabric once per neighbour (329 MB fetched per launch against 157 MB of input, PMC round 3); here each XCD takes a
+    // contiguous run of tiles (whole strips of an image)
+    int tile;
+    {
+        const int total = (int)gridDim.x, lin = (int)blockIdx.x;
+        const int xcd = lin & 7, q = total >> 3, r = total & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        tile = base + (lin >> 3);
+    }
     const int tw = tile % tiles_w; tile /= tiles_w;
     const int th = tile % tiles_h; tile /= tiles_h;
     const int64_t img = tile;                              // image index over groups x batch (camera-major)
