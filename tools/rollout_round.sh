@@ -1,6 +1,6 @@
 # end-to-end eval rollouts through imitate_episodes.py (SyntheticEnv, 3 cams, temporal ensembling, incl. H2D / D2H) + the eval-shard bench mode
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/rollout_r02
+O=$R/gpurun_out/rollout_r03
 mkdir -p $O
 cd $R/act-plus-plus_amd
 COMMON="--eval --task_name sim_transfer_cube_scripted --ckpt_dir $O/ck --policy_class ACT --kl_weight 10 --chunk_size 100 --hidden_dim 512 --batch_size 8 --dim_feedforward 3200 --num_steps 1 --lr 1e-5 --seed 0 --temporal_agg --synthetic_env"
