@@ -180,6 +180,12 @@ class DiffusionNet:
                 if bi == 0 and li > 1:
                     blk["ds"] = stack_conv(q + "downsample.0.weight")
                     blk["gd"] = (stack_vec(q + "downsample.1.weight"), stack_vec(q + "downsample.1.bias"))
+                if li == 1 and self.prec == "f16x3":
+                    # layer1 (64 -> 64 channels) runs on the direct convolution kernel of the ACT trunk (conv3.hip: the
+                    # implicit GEMM is L2-traffic bound at 64 output channels); its split weight images are built once here
+                    blk["c1_16"], blk["c2_16"] = ops.split16(blk["c1"], 256.0), ops.split16(blk["c2"], 256.0)
+                    blk["ones"] = torch.ones(ncam, 64, device=d)
+                    blk["zeros"] = torch.zeros(ncam, 64, device=d)
                 w[f"l{li}b{bi}"] = blk
         w["kp"] = torch.stack([t[f"policy.pools.{i}.nets.weight"].permute(0, 2, 3, 1) for i in range(ncam)]).contiguous().to(d)
         w["kp_b"] = torch.stack([t[f"policy.pools.{i}.nets.bias"] for i in range(ncam)]).contiguous().to(d)
@@ -244,8 +250,12 @@ class DiffusionNet:
             for bi in range(2):
                 blk = w[f"l{li}b{bi}"]
                 s = 2 if (li > 1 and bi == 0) else 1
-                y = self._gn_maps(self._conv(x, blk["c1"], s, 1), blk["g1"])
-                y = self._conv(y, blk["c2"], 1, 1)
+                if "c1_16" in blk:
+                    y = self._gn_maps(ops.conv3x3_c64(x, blk["c1"], blk["ones"], blk["zeros"], w16=blk["c1_16"]), blk["g1"])
+                    y = ops.conv3x3_c64(y, blk["c2"], blk["ones"], blk["zeros"], w16=blk["c2_16"])
+                else:
+                    y = self._gn_maps(self._conv(x, blk["c1"], s, 1), blk["g1"])
+                    y = self._conv(y, blk["c2"], 1, 1)
                 idt = x
                 if "ds" in blk:
                     idt = self._gn_maps(self._conv(x, blk["ds"], s, 0), blk["gd"], relu=False)
@@ -263,14 +273,16 @@ class DiffusionNet:
         pad = k // 2 if pad is None else pad
         cols = ops.unfold1d(x, k, stride, pad, transposed)
         To = cols.shape[1]
-        y = ops.gemm(cols.reshape(B * To, k * Cc), self.w[wk], bias=self.w[bk], prec=self.prec, b_scale=self.bs)
+        # (small grids with long contractions -- 256..1024 rows x K up to 5120 -- are split over K: the UNet pass is these)
+        y = ops.gemm(cols.reshape(B * To, k * Cc), self.w[wk], bias=self.w[bk], prec=self.prec, b_scale=self.bs, splitk="auto")
         return y.reshape(B, To, -1)
 
     def _crb(self, p, x, gm, k=5):
         w = self.w
         B = x.shape[0]
         y = self._conv1d(x, p + "blocks.0.block.0.weight", p + "blocks.0.block.0.bias", k)
-        emb = ops.gemm(gm, w[p + "cond_encoder.1.weight"], bias=w[p + "cond_encoder.1.bias"], prec=self.prec, b_scale=self.bs)     # [B][2*out]
+        emb = ops.gemm(gm, w[p + "cond_encoder.1.weight"], bias=w[p + "cond_encoder.1.bias"], prec=self.prec, b_scale=self.bs,
+                       splitk="auto")     # [B][2*out]
         oc = y.shape[-1]
         y = ops.groupnorm(y, w[p + "blocks.0.block.1.weight"], w[p + "blocks.0.block.1.bias"], 8, act="mish",
                           film=(emb[:, :oc], emb[:, oc:]))

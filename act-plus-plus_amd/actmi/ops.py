@@ -46,6 +46,20 @@ def pow2_scale(x):
     return out
 
 
+def auto_splitk(M, N, K):
+    """Split factor for a product whose grid is too small to fill 256 CUs while every workgroup walks a long contraction (the
+    engine's rule for its own small-batch launches, engine.hip:ctx_gemm): aim at 1536 64x64-tile equivalents, keep >= 12 K
+    tiles of 32 per split, at most 8 splits; 0 = do not split."""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    nk = (K + 31) // 32
+    if tiles >= 768 or nk < 24:
+        return 0
+    s = min(8, (1536 + tiles - 1) // tiles, nk // 12)
+    while s >= 2 and (s - 1) * ((nk + s - 1) // s) >= nk:
+        s -= 1
+    return s if s >= 2 else 0
+
+
 def gemm(A, W, bias=None, scale=None, res=None, res_mod=0, relu=False, a_add=None, add_mod=0, add_ncols=0, rowmap=None,
          out=None, out_rows=None, drop_p=0.0, drop_seed=0, prec=None, w_split=False, a_scale=0.0, b_scale=0.0,
          a_scale_dev=None, b_scale_dev=None, splitk=0):
@@ -55,6 +69,9 @@ def gemm(A, W, bias=None, scale=None, res=None, res_mod=0, relu=False, a_add=Non
     lib = L.load()
     M, K = A.shape
     N = W.shape[0]
+    if splitk == "auto":
+        splitk = auto_splitk(M, N, K) if (rowmap is None and not res_mod and not drop_p and N % 4 == 0 and a_scale_dev is None
+                                          and b_scale_dev is None) else 0
     if splitk and splitk > 1:
         assert rowmap is None and not res_mod and not drop_p
         part = torch.empty((splitk, M, N), dtype=torch.float32, device=A.device)
@@ -267,13 +284,15 @@ def sample_onehot(logits, temperature=1.0, seed=0, want_probs=False):
     return (code, probs) if want_probs else code
 
 
-def conv3x3_c64(x, w_ohwi, scale=None, bias=None, res=None, relu=False, w_scale=256.0):
-    """direct 3x3/s1/p1 conv, 64 -> 64 channels, f16x3: x [G,B,H,W,64]; w_ohwi [G,64,3,3,64]; returns [G,B,H,W,64]."""
+def conv3x3_c64(x, w_ohwi, scale=None, bias=None, res=None, relu=False, w_scale=256.0, w16=None):
+    """direct 3x3/s1/p1 conv, 64 -> 64 channels, f16x3: x [G,B,H,W,64]; w_ohwi [G,64,3,3,64]; returns [G,B,H,W,64].
+    w16: the split image of w_ohwi built with w_scale (split16) when the caller keeps one; else it is built per call."""
     lib = L.load()
     G, B, H, W, Cin = x.shape
     assert Cin == 64 and tuple(w_ohwi.shape[1:]) == (64, 3, 3, 64)
     out = torch.empty_like(x)
-    w16 = split16(w_ohwi, w_scale)
+    if w16 is None:
+        w16 = split16(w_ohwi, w_scale)
     scale = scale if scale is not None else torch.ones(G, 64, device=x.device)
     bias = bias if bias is not None else torch.zeros(G, 64, device=x.device)
     L.check(lib.actmi_op_conv3x3_c64(_p(x.contiguous()), _p(w16), float(w_scale), _p(scale.contiguous()), _p(bias.contiguous()),
