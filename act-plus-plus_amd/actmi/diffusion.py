@@ -171,6 +171,10 @@ class DiffusionNet:
         def stack_vec(suffix):
             return torch.stack([t[f"policy.backbones.{i}.nets.{suffix}"] for i in range(ncam)]).contiguous().to(d)
         w["stem"] = stack_conv("0.weight")
+        if self.prec == "f16x3":
+            # u8 frames: the stem on the ACT path's 7x7 kernel (its lookup table holds v / 255 here, no ImageNet normalisation,
+            # and no ReLU: GroupNorm comes first) instead of a K = 196 implicit GEMM with 64 output channels
+            w["stem_ws"] = ops.conv1_prepare(torch.stack([t[f"policy.backbones.{i}.nets.0.weight"] for i in range(ncam)]).to(d), lut_mode=1)
         w["stem_gn"] = (stack_vec("1.weight"), stack_vec("1.bias"))
         for li in range(1, 5):
             for bi in range(2):
@@ -237,11 +241,14 @@ class DiffusionNet:
     @_on_own_device
     def obs_cond(self, qpos, image_u8):
         w = self.w
-        if image_u8.dtype == torch.uint8:
-            x = ops.u8_to_nhwc4(image_u8)                                 # [cam][B][H][W][4] in [0,1]: no ImageNet normalisation here
-        else:                                                             # f32 [B][cam][3][H][W] in [0,1] (the reference's contract)
-            x = torch.nn.functional.pad(image_u8.to(torch.float32).permute(1, 0, 3, 4, 2), (0, 1)).contiguous()
-        x = self._conv(x, w["stem"], 2, 3)
+        if image_u8.dtype == torch.uint8 and "stem_ws" in w:
+            x = ops.conv1_prepared(image_u8, w["stem_ws"], 64, relu=False)
+        else:
+            if image_u8.dtype == torch.uint8:
+                x = ops.u8_to_nhwc4(image_u8)                             # [cam][B][H][W][4] in [0,1]: no ImageNet normalisation here
+            else:                                                         # f32 [B][cam][3][H][W] in [0,1] (the reference's contract)
+                x = torch.nn.functional.pad(image_u8.to(torch.float32).permute(1, 0, 3, 4, 2), (0, 1)).contiguous()
+            x = self._conv(x, w["stem"], 2, 3)
         x = self._gn_maps(x, w["stem_gn"])
         ncam_, B_ = x.shape[0], x.shape[1]
         x = ops.maxpool3x3s2(x.reshape(ncam_ * B_, *x.shape[2:]))

@@ -139,6 +139,9 @@ def load():
         "actmi_op_layernorm": ([vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp], i32),
         "actmi_op_maxpool3x3s2": ([vp, vp, i32, i32, i32, i32, vp], i32),
         "actmi_op_conv1": ([vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+        "actmi_op_conv1_workspace_floats": ([i32, i32], C.c_int64),
+        "actmi_op_conv1_prepare": ([vp, vp, i32, i32, i32, vp], i32),
+        "actmi_op_conv1_prepared": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
         "actmi_op_conv3x3_c64": ([vp, vp, C.c_float, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
         "actmi_op_wgrad7x7s2": ([vp, vp, vp, vp, C.c_int64, vp, i32, i32, i32, i32, vp], i32),
         "actmi_op_wgrad3x3_c64": ([vp, vp, vp, vp, C.c_int64, vp, i32, i32, i32, i32, vp], i32),

@@ -284,6 +284,28 @@ def sample_onehot(logits, temperature=1.0, seed=0, want_probs=False):
     return (code, probs) if want_probs else code
 
 
+def conv1_prepare(w_oihw, lut_mode=1):
+    """prepared stem weights (actmi_op_conv1_prepare): w_oihw [C, Cout, 3, 7, 7]; lut_mode 0 = the ACT path's ImageNet
+    normalisation of the u8 pixels, 1 = v / 255 only.  Returns the workspace tensor to hand to conv1_prepared."""
+    lib = L.load()
+    w_oihw = w_oihw.contiguous()
+    Cc, Cout = w_oihw.shape[0], w_oihw.shape[1]
+    ws = torch.zeros(int(lib.actmi_op_conv1_workspace_floats(Cc, Cout)), dtype=torch.float32, device=w_oihw.device)
+    L.check(lib.actmi_op_conv1_prepare(_p(w_oihw), _p(ws), Cc, Cout, int(lut_mode), L.current_stream_ptr()), None, "op_conv1_prepare")
+    return ws
+
+
+def conv1_prepared(image_u8, ws, Cout, relu=False, scale=None, bias=None):
+    """the 7x7 / s2 stem on prepared weights: image u8 [B, C, H, W, 3] -> [C, B, Ho, Wo, Cout] (f16x3); launch only."""
+    lib = L.load()
+    image_u8 = image_u8.contiguous()
+    B, Cc, H, W, _ = image_u8.shape
+    out = torch.empty((Cc, B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cout), dtype=torch.float32, device=image_u8.device)
+    L.check(lib.actmi_op_conv1_prepared(_p(image_u8), _p(ws), _p(scale), _p(bias), _p(out), B, Cc, H, W, Cout, 1 if relu else 0,
+                                        L.current_stream_ptr()), None, "op_conv1_prepared")
+    return out
+
+
 def conv3x3_c64(x, w_ohwi, scale=None, bias=None, res=None, relu=False, w_scale=256.0, w16=None):
     """direct 3x3/s1/p1 conv, 64 -> 64 channels, f16x3: x [G,B,H,W,64]; w_ohwi [G,64,3,3,64]; returns [G,B,H,W,64].
     w16: the split image of w_ohwi built with w_scale (split16) when the caller keeps one; else it is built per call."""

@@ -2,6 +2,7 @@
 #include "engine.h"
 
 #include <cstring>
+#include <vector>
 
 namespace {
 thread_local std::string g_op_error;
@@ -312,6 +313,52 @@ int actmi_op_conv1(const void* image, int image_fmt, const float* w_oihw, const 
     a.image = image; a.fmt = image_fmt; a.lut = lut; a.w = wp; a.scale = scale; a.bias = bias; a.out = out;
     a.B = B; a.C = C; a.H = H; a.W = W; a.Ho = (H + 6 - 7) / 2 + 1; a.Wo = (W + 6 - 7) / 2 + 1; a.Cout = Cout;
     a.prec = prec;
+    return launch_conv1(a, S(stream), &g_op_error);
+}
+
+// workspace layout of the prepared stem: [C*Cout*148 repacked weights][768 lut][C*Cout ones][C*Cout zeros][C * wimg bytes]
+static int64_t conv1_ws_off_lut(int C, int Cout) { return (int64_t)C * Cout * 148; }
+int64_t actmi_op_conv1_workspace_floats(int C, int Cout) {
+    return conv1_ws_off_lut(C, Cout) + 768 + 2 * (int64_t)C * Cout + (int64_t)C * ((conv1_wimg_bytes() + 3) / 4) + 16;
+}
+int actmi_op_conv1_prepare(const float* w_oihw, float* workspace, int C, int Cout, int lut_mode, void* stream) {
+    g_op_error.clear();
+    if (!w_oihw || !workspace || C < 1 || Cout < 1 || Cout > 64) { g_op_error = "conv1_prepare: bad argument"; return ACTMI_E_INVALID; }
+    float* lut = workspace + conv1_ws_off_lut(C, Cout);
+    float* ones = lut + 768;
+    float* zeros = ones + (int64_t)C * Cout;
+    float* wimg = zeros + (int64_t)C * Cout;
+    wimg = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(wimg) + 15) & ~(uintptr_t)15);
+    int rc = launch_repack_conv_w(w_oihw, workspace, C, Cout, 3, 7, 7, (int64_t)Cout * 147, (int64_t)Cout * 148, 148, S(stream));
+    if (rc) return ACTMI_E_LAUNCH;
+    std::vector<float> host(768 + 2 * (size_t)C * Cout);
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int c = 0; c < 3; ++c)
+        for (int v = 0; v < 256; ++v) {
+            const float x = (float)((double)v / 255.0);
+            host[c * 256 + v] = lut_mode == 0 ? (x - mean[c]) / stdv[c] : x;
+        }
+    for (int i = 0; i < C * Cout; ++i) { host[768 + i] = 1.f; host[768 + C * Cout + i] = 0.f; }
+    if (hipMemcpyAsync(lut, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, S(stream)) != hipSuccess) return ACTMI_E_LAUNCH;
+    rc = launch_conv1_wimg(workspace, wimg, C, Cout, S(stream), 256.f);
+    if (rc) return ACTMI_E_LAUNCH;
+    if (hipStreamSynchronize(S(stream)) != hipSuccess) return ACTMI_E_LAUNCH;
+    return 0;
+}
+int actmi_op_conv1_prepared(const void* image_u8, const float* workspace, const float* scale, const float* bias, float* out, int B,
+                            int C, int H, int W, int Cout, int relu, void* stream) {
+    g_op_error.clear();
+    if (!image_u8 || !workspace || !out) { g_op_error = "conv1_prepared: null pointer"; return ACTMI_E_INVALID; }
+    const float* lut = workspace + conv1_ws_off_lut(C, Cout);
+    const float* ones = lut + 768;
+    const float* zeros = ones + (int64_t)C * Cout;
+    const float* wimg = zeros + (int64_t)C * Cout;
+    wimg = reinterpret_cast<const float*>((reinterpret_cast<uintptr_t>(wimg) + 15) & ~(uintptr_t)15);
+    Conv1Args a;
+    a.image = image_u8; a.fmt = ACTMI_IMG_U8_NHWC; a.lut = lut; a.w = workspace; a.scale = scale ? scale : ones; a.bias = bias ? bias : zeros;
+    a.out = out; a.B = B; a.C = C; a.H = H; a.W = W; a.Ho = (H + 6 - 7) / 2 + 1; a.Wo = (W + 6 - 7) / 2 + 1; a.Cout = Cout;
+    a.prec = ACTMI_PREC_F16X3; a.wimg = reinterpret_cast<const unsigned char*>(wimg); a.wscale = 256.f;
+    a.relu_floor = relu ? 0.f : -__builtin_inff();
     return launch_conv1(a, S(stream), &g_op_error);
 }
 

@@ -72,6 +72,7 @@ struct Conv1Args {
     int vpool_nseg = 1;   // set by the launcher
     float wscale = 256.f; // f16x3 only: power of two the split weight image was built with (undone in the epilogue)
     int cam0 = 0, ncam = 0;   // camera range of this launch (ncam = 0: all C); image / w / scale / bias / out stay whole-tensor pointers
+    float relu_floor = 0.f;   // f16x3, plain (non-vpool) form: out = max(acc * scale + bias, relu_floor); -inf = no ReLU
 };
 int64_t conv1_wimg_bytes();
 int launch_conv1_wimg(const float* w, void* img, int C, int Cout, hipStream_t st, float wscale = 256.f);

@@ -528,10 +528,10 @@ __global__ __launch_bounds__(256) void conv1_f16x3_kernel(Conv1Args p, int tiles
                     const int n = nt * 32 + li;
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
-                        float r0 = fmaxf(acc[nt][4 * gq + 0] * sc[nt] + bi[nt], 0.f);
-                        float r1 = fmaxf(acc[nt][4 * gq + 1] * sc[nt] + bi[nt], 0.f);
-                        float r2 = fmaxf(acc[nt][4 * gq + 2] * sc[nt] + bi[nt], 0.f);
-                        float r3 = fmaxf(acc[nt][4 * gq + 3] * sc[nt] + bi[nt], 0.f);
+                        float r0 = fmaxf(acc[nt][4 * gq + 0] * sc[nt] + bi[nt], p.relu_floor);
+                        float r1 = fmaxf(acc[nt][4 * gq + 1] * sc[nt] + bi[nt], p.relu_floor);
+                        float r2 = fmaxf(acc[nt][4 * gq + 2] * sc[nt] + bi[nt], p.relu_floor);
+                        float r3 = fmaxf(acc[nt][4 * gq + 3] * sc[nt] + bi[nt], p.relu_floor);
                         if (vec_ok) {
                             quad_transpose(r0, r1, r2, r3, k);
                             const int wo = wo0 + phalf * 32 + 8 * gq + 4 * lh + k;

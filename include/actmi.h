@@ -354,6 +354,16 @@ int actmi_op_maxpool3x3s2(const float* in_nhwc, float* out_nhwc, int nimg, int H
 int actmi_op_conv1(const void* image, int image_fmt, const float* w_oihw, const float* scale, const float* bias,
                    float* out, float* workspace /* >= C*Cout*148 + 768 floats */, int B, int C, int H, int W, int Cout,
                    int prec /* ACTMI_PREC_*, 0 = environment / native fp32 */, void* stream);
+/* The same stem for callers that keep its prepared weights (and may want it without the ACT path's ImageNet normalisation or
+ * ReLU: the DiffusionPolicy trunk applies GroupNorm between the convolution and the ReLU and feeds x / 255 un-normalised,
+ * policy.py:150-170): actmi_op_conv1_prepare fills `workspace` (>= actmi_op_conv1_workspace_floats(C, Cout) floats) once --
+ * repacked weights, the f16x3 LDS weight image, the u8 lookup table (lut_mode 0: ((v / 255) - mean) / std as the ACT path,
+ * 1: v / 255), unit scale / zero bias -- and synchronises; actmi_op_conv1_prepared then only launches (graph-capturable): out =
+ * act(conv * scale + bias), scale / bias NULL = 1 / 0, relu 0 = no activation (f16x3 only).  u8 NHWC images. */
+int64_t actmi_op_conv1_workspace_floats(int C, int Cout);
+int actmi_op_conv1_prepare(const float* w_oihw, float* workspace, int C, int Cout, int lut_mode, void* stream);
+int actmi_op_conv1_prepared(const void* image_u8, const float* workspace, const float* scale, const float* bias, float* out,
+                            int B, int C, int H, int W, int Cout, int relu, void* stream);
 /* direct 3x3 / stride 1 / pad 1 convolution for 64 -> 64 channels (ResNet18 layer1), f16x3: x camera-major NHWC
  * [G][B][H][W][64]; w16 = actmi_op_split16 image (built with w_scale) of the weights [G][64][3][3][64] (cout, r, s, cin);
  * out = act(conv * scale + bias (+ res)) */
