@@ -392,10 +392,12 @@ class ACTEngine:
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         buckets, tails = self._shard_plan(world, bucket_mb * (1 << 20) // 4)
         arena = self.grad_arena()
-        cur = torch.cuda.current_stream(self.device)
-        if not hasattr(self, "_comm_stream"):
-            self._comm_stream = torch.cuda.Stream(device=self.device)
-        side = self._comm_stream
+        on_gpu = arena.is_cuda                 # (a CPU stand-in of the engine drives the same plan in the gloo tests)
+        if on_gpu:
+            cur = torch.cuda.current_stream(self.device)
+            if not hasattr(self, "_comm_stream"):
+                self._comm_stream = torch.cuda.Stream(device=self.device)
+            side = self._comm_stream
 
         def rs(lo, hi):
             k = (hi - lo) // world
@@ -403,7 +405,7 @@ class ACTEngine:
             if comm_dtype is None:
                 return reduce_scatter_flat(own, arena[lo:hi], group), None
             src = arena[lo:hi].to(comm_dtype)
-            dst = torch.empty(k, dtype=comm_dtype, device=self.device)
+            dst = torch.empty(k, dtype=comm_dtype, device=arena.device)
             return reduce_scatter_flat(dst, src, group), (own, dst, src)
 
         def finish(works):
@@ -411,13 +413,17 @@ class ACTEngine:
                 w.wait()
                 if cast is not None:
                     cast[0].copy_(cast[1])
-        L.check(self.lib.actmi_wait_grad_phase(self.h, 1, C.c_void_p(side.cuda_stream)), self.h, "wait_grad_phase")
-        with torch.cuda.stream(side):
-            finish([rs(lo, hi) for lo, hi, ph in buckets if ph == 1])            # under the rest of the backward
+        if on_gpu:
+            L.check(self.lib.actmi_wait_grad_phase(self.h, 1, C.c_void_p(side.cuda_stream)), self.h, "wait_grad_phase")
+            with torch.cuda.stream(side):
+                finish([rs(lo, hi) for lo, hi, ph in buckets if ph == 1])        # under the rest of the backward
+        else:
+            finish([rs(lo, hi) for lo, hi, ph in buckets if ph == 1])
         finish([rs(lo, hi) for lo, hi, ph in buckets if ph == 2])
         for lo, hi in tails:
             dist.all_reduce(arena[lo:hi], op=dist.ReduceOp.SUM, group=group)
-        cur.wait_stream(side)
+        if on_gpu:
+            cur.wait_stream(side)
         self.sync_flags(group)
         self._shard = (world, rank, buckets, tails, group)
 
@@ -462,7 +468,7 @@ class ACTEngine:
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return
         f = self.flags_tensor()
-        shifts = torch.arange(3, dtype=torch.int32, device=self.device)
+        shifts = torch.arange(3, dtype=torch.int32, device=f.device)
         bits = (f >> shifts) & 1
         dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=group)
         f.copy_((bits << shifts).sum(dtype=torch.int32).reshape(1) | f)
