@@ -55,25 +55,6 @@ class GemmDesc(C.Structure):
     ]
 
 
-class Gemm16Desc(C.Structure):
-    """actmi_gemm16_desc (include/actmi.h): GEMM / implicit-GEMM convolution on pre-split ("s16") operands."""
-    _fields_ = [
-        ("A", C.c_void_p), ("lda", C.c_int64), ("mode", C.c_int32),
-        ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
-        ("stride", C.c_int32), ("pad", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
-        ("img_stride", C.c_int64),
-        ("Bw", C.c_void_p), ("ldb", C.c_int64), ("alpha", C.c_float),
-        ("scale", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("ldres", C.c_int64),
-        ("res_fmt", C.c_int32), ("res_mod", C.c_int32), ("res_scale", C.c_float), ("relu", C.c_int32),
-        ("C", C.c_void_p), ("ldc", C.c_int64), ("c_fmt", C.c_int32), ("c_scale", C.c_float),
-        ("rowmap", C.c_void_p),
-        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("groups", C.c_int32),
-        ("gA", C.c_int64), ("gB", C.c_int64), ("gSB", C.c_int64), ("gC", C.c_int64), ("gRes", C.c_int64),
-        ("splitk", C.c_int32), ("split_stride", C.c_int64),
-        ("zero_page", C.c_void_p), ("flag", C.c_void_p), ("bm", C.c_int32), ("stamps", C.c_void_p),
-    ]
-
-
 class AttnDesc(C.Structure):
     _fields_ = [
         ("Q", C.c_void_p), ("q_bs", C.c_int64), ("q_rs", C.c_int64),
@@ -131,9 +112,6 @@ def load():
         "actmi_op_permute_conv_k": ([vp, vp, C.c_int64, i32, i32, i32, vp], i32),
         "actmi_op_sample_onehot": ([vp, i32, i32, C.c_float, C.c_uint64, vp, vp, vp], i32),
         "actmi_op_pow2_scale": ([vp, C.c_int64, i32, i32, vp, vp], i32),
-        "actmi_op_split16v2": ([vp, vp, C.c_int64, C.c_float, vp], i32),
-        "actmi_op_unsplit16v2": ([vp, vp, C.c_int64, C.c_float, vp], i32),
-        "actmi_op_gemm16": ([C.POINTER(Gemm16Desc), vp], i32),
         "actmi_op_splitk_combine": ([vp, i32, C.c_int64, C.c_int64, i32, i32, vp, vp, vp, C.c_int64, i32, vp, C.c_int64, vp], i32),
         "actmi_op_attention": ([C.POINTER(AttnDesc), vp], i32),
         "actmi_op_layernorm": ([vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp], i32),
@@ -145,7 +123,6 @@ def load():
         "actmi_op_conv3x3_c64": ([vp, vp, C.c_float, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
         "actmi_op_wgrad7x7s2": ([vp, vp, vp, vp, C.c_int64, vp, i32, i32, i32, i32, vp], i32),
         "actmi_op_wgrad3x3_c64": ([vp, vp, vp, vp, C.c_int64, vp, i32, i32, i32, i32, vp], i32),
-        "actmi_op_conv3x3_direct": ([vp, vp, C.c_float, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
         "actmi_op_groupnorm": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp, C.c_int64, vp], i32),
         "actmi_op_spatial_softmax": ([vp, vp, i32, i32, i32, i32, f32, vp], i32),
         "actmi_op_unfold1d": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),

@@ -10,7 +10,7 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-PREC = {None: 0, "f32": 1, "f16x3": 2}
+PREC = {None: 0, "f32": 1, "f16x3": 2, "bf16": 3}
 
 
 def split16(w, scale=1.0):
@@ -114,89 +114,6 @@ def gemm(A, W, bias=None, scale=None, res=None, res_mod=0, relu=False, a_add=Non
     d.a_scale_dev = a_scale_dev.data_ptr() if a_scale_dev is not None else None
     d.b_scale_dev = b_scale_dev.data_ptr() if b_scale_dev is not None else None
     L.check(lib.actmi_op_gemm(C.byref(d), L.current_stream_ptr()), None, "op_gemm")
-    return out
-
-
-def split16v2(x, scale=1.0):
-    """"s16" form of an f32 cuda tensor whose last dimension is a multiple of 8 (gemm16 operands): same shape / strides, every
-    aligned group of 8 floats replaced by [8 fp16 hi][8 fp16 lo] of (x * scale).  Returned as an f32-typed tensor of raw bits."""
-    lib = L.load()
-    x = x.contiguous()
-    out = torch.empty_like(x)
-    L.check(lib.actmi_op_split16v2(_p(x), _p(out), x.numel(), float(scale), L.current_stream_ptr()), None, "op_split16v2")
-    return out
-
-
-def unsplit16v2(x16, scale=1.0):
-    """inverse of split16v2: (hi + lo) / scale."""
-    lib = L.load()
-    out = torch.empty_like(x16)
-    L.check(lib.actmi_op_unsplit16v2(_p(x16), _p(out), x16.numel(), float(scale), L.current_stream_ptr()), None,
-            "op_unsplit16v2")
-    return out
-
-
-_ZERO_PAGE = {}
-
-
-def _zero_page(dev):
-    if dev not in _ZERO_PAGE:
-        _ZERO_PAGE[dev] = torch.zeros(64, dtype=torch.float32, device=dev)
-    return _ZERO_PAGE[dev]
-
-
-def gemm16(A16, W16, alpha=1.0, bias=None, scale=None, res=None, res_fmt="s16", res_mod=0, res_scale=1.0, relu=False,
-           out_fmt="s16", out_scale=1.0, rowmap=None, out_rows=None, bm=0, splitk=0, conv=None, flag=None, out=None,
-           _ld_override=None, stamps=None):
-    """Forward GEMM on pre-split operands.  A16 [M,K] (or, with conv=dict(stride, pad, KH, KW), NHWC images [G,B,H,W,Cin]),
-    W16 [N,K] (conv: [G,Cout,KH,KW,Cin]), both from split16v2; alpha = 1 / (scale of A * scale of W).
-    Returns an s16 tensor holding (value * out_scale) or, with out_fmt="f32", plain floats.  splitk > 1 returns the f32 slices
-    [splitk, M, N] (sum them to get the product * alpha)."""
-    lib = L.load()
-    d = L.Gemm16Desc()
-    if conv is not None:
-        G, B, H, W, Cin = A16.shape
-        _, Cout, KH, KW, _ = W16.shape
-        stride, pad = conv["stride"], conv["pad"]
-        Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-        M, N, K = B * Ho * Wo, Cout, KH * KW * Cin
-        d.mode = 1
-        d.H, d.W, d.Cin, d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo = H, W, Cin, KH, KW, stride, pad, Ho, Wo
-        d.img_stride, d.lda = H * W * Cin, Cin
-        d.groups, d.gA, d.gB, d.gSB = G, B * H * W * Cin, Cout * K, Cout
-        d.gC = d.gRes = M * N
-        d.zero_page = _zero_page(A16.device).data_ptr()
-        oshape = (G, B, Ho, Wo, Cout)
-        ldc = N
-    else:
-        M, K = A16.shape
-        N = W16.shape[0]
-        d.mode, d.lda, d.groups = 0, A16.stride(0), 1
-        oshape = (out_rows or M, N)
-        ldc = N
-    d.A, d.Bw, d.ldb = A16.data_ptr(), W16.data_ptr(), K
-    if _ld_override is not None:           # diagnostics: (lda, ldb) e.g. (0, 0) makes every row the same cache-resident line
-        d.lda, d.ldb = _ld_override
-    d.alpha = float(alpha)
-    d.scale = scale.data_ptr() if scale is not None else None
-    d.bias = bias.data_ptr() if bias is not None else None
-    if res is not None:
-        d.res, d.ldres, d.res_fmt, d.res_mod, d.res_scale = res.data_ptr(), N, 1 if res_fmt == "s16" else 0, res_mod, res_scale
-    d.relu = 1 if relu else 0
-    d.M, d.N, d.K = M, N, K
-    d.bm = bm
-    d.flag = flag.data_ptr() if flag is not None else None
-    d.stamps = stamps.data_ptr() if stamps is not None else None
-    if splitk and splitk > 1:
-        out = torch.empty((splitk,) + tuple(oshape), dtype=torch.float32, device=A16.device)
-        d.splitk, d.split_stride, d.c_fmt = int(splitk), (d.groups * M * N), 0
-    else:
-        if out is None:
-            out = torch.zeros(oshape, dtype=torch.float32, device=A16.device)
-        d.c_fmt, d.c_scale = (1 if out_fmt == "s16" else 0), float(out_scale)
-        d.rowmap = rowmap.data_ptr() if rowmap is not None else None
-    d.C, d.ldc = out.data_ptr(), ldc
-    L.check(lib.actmi_op_gemm16(C.byref(d), L.current_stream_ptr()), None, "op_gemm16")
     return out
 
 
@@ -351,18 +268,6 @@ def wgrad7x7s2(dy, x4, dy_scale=None):
             None, "op_wgrad7x7s2")
     return dw
 
-
-def conv3x3_direct(x, w_ohwi, scale, bias, res=None, relu=False, w_scale=256.0):
-    """direct 3x3 / stride 1 / pad 1 convolution, Cin and Cout multiples of 64 (f16x3): x [G,B,H,W,Cin], w_ohwi [G,Cout,3,3,Cin]."""
-    lib = L.load()
-    G, B, H, W, Cin = x.shape
-    Cout = w_ohwi.shape[1]
-    w16 = split16(w_ohwi, w_scale)
-    out = torch.empty((G, B, H, W, Cout), dtype=torch.float32, device=x.device)
-    L.check(lib.actmi_op_conv3x3_direct(_p(x.contiguous()), _p(w16), float(w_scale), _p(scale.contiguous()), _p(bias.contiguous()),
-                                        _p(res.contiguous() if res is not None else None), _p(out), G, B, H, W, Cin, Cout,
-                                        1 if relu else 0, L.current_stream_ptr()), None, "op_conv3x3_direct")
-    return out
 
 
 def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False, split=True, drop_p=0.0, drop_seed=0, prec=None,

@@ -234,25 +234,8 @@ int actmi_op_permute_conv_k(const float* src, float* dst, int64_t rows, int taps
     return rc == 0 ? 0 : (rc == -2 ? ACTMI_E_INVALID : ACTMI_E_LAUNCH);
 }
 
-int actmi_op_split16v2(const float* src, void* dst, int64_t nfloats, float scale, void* stream) {
-    g_op_error.clear();
-    const int rc = launch_split16v2(src, dst, nfloats, scale, S(stream));
-    if (rc != 0) g_op_error = "split16v2: nfloats must be a multiple of 8 and both pointers 16-byte aligned";
-    return rc == 0 ? 0 : ACTMI_E_INVALID;
-}
 
-int actmi_op_unsplit16v2(const void* src, float* dst, int64_t nfloats, float scale, void* stream) {
-    g_op_error.clear();
-    const int rc = launch_unsplit16v2(src, dst, nfloats, scale, S(stream));
-    if (rc != 0) g_op_error = "unsplit16v2: nfloats must be a multiple of 8, pointers 16-byte aligned, scale > 0";
-    return rc == 0 ? 0 : ACTMI_E_INVALID;
-}
 
-int actmi_op_gemm16(const actmi_gemm16_desc* d, void* stream) {
-    if (!d) return ACTMI_E_INVALID;
-    g_op_error.clear();
-    return launch_gemm16(*d, S(stream), &g_op_error);
-}
 
 int actmi_op_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, void* stream) {
     g_op_error.clear();
@@ -371,14 +354,6 @@ int actmi_op_conv3x3_c64(const float* x, const float* w16, float w_scale, const 
     return launch_conv3x3_c64(a, S(stream), &g_op_error);
 }
 
-int actmi_op_conv3x3_direct(const float* x, const float* w16, float w_scale, const float* scale, const float* bias,
-                            const float* res, float* out, int G, int B, int H, int W, int Cin, int Cout, int relu, void* stream) {
-    g_op_error.clear();
-    Conv3gArgs a;
-    a.x = x; a.w16 = w16; a.scale = scale; a.bias = bias; a.res = res; a.out = out;
-    a.G = G; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu; a.w_scale = w_scale;
-    return launch_conv3x3_direct(a, S(stream), &g_op_error);
-}
 
 int actmi_op_wgrad3x3_c64(const float* dy, const float* x, float* dw, float* ws, int64_t ws_floats, const float* dy_scale_dev, int G,
                           int B, int H, int W, void* stream) {

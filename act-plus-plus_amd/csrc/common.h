@@ -49,13 +49,6 @@ struct SplitCombineArgs {
 };
 int launch_splitk_combine(const SplitCombineArgs& a, hipStream_t st);
 
-// ---- forward GEMM / implicit-GEMM convolution on pre-split ("s16") operands (gemm16.hip): descriptor is part of the C ABI
-typedef actmi_gemm16_desc Gemm16Args;
-int launch_gemm16(const Gemm16Args& a, hipStream_t st, std::string* err);
-int gemm16_pick_bm(int M, int N, int groups, int splitk);
-int launch_split16v2(const float* src, void* dst, int64_t nfloats, float scale, hipStream_t st);
-int launch_unsplit16v2(const void* src, float* dst, int64_t nfloats, float scale, hipStream_t st);
-
 // ---- conv1 7x7/s2 + FrozenBN + ReLU (conv1.hip) -----------------------------------------------
 struct Conv1Args {
     const void* image;    // u8 NHWC [B][C][H][W][3] or f32 NCHW [B][C][3][H][W]
@@ -97,19 +90,6 @@ struct Conv3Args {
     unsigned* amax_out = nullptr;
 };
 int launch_conv3x3_c64(const Conv3Args& a, hipStream_t st, std::string* err);
-
-// ---- direct 3x3 / stride 1 / pad 1 convolution, Cin and Cout multiples of 64, f16x3 (conv3g.hip) ----------
-struct Conv3gArgs {
-    const float* x;       // camera-major NHWC [G][B][H][W][Cin]
-    const float* w16;     // fp16-split image (actmi_op_split16) of the weights [G][Cout][(r,s,c) = 9*Cin], built with w_scale
-    const float* scale;   // [G][Cout] folded FrozenBN
-    const float* bias;    // [G][Cout]
-    const float* res;     // optional residual, same shape as out
-    float* out;           // [G][B][H][W][Cout]
-    int G, B, H, W, Cin, Cout, relu;
-    float w_scale;
-};
-int launch_conv3x3_direct(const Conv3gArgs& a, hipStream_t st, std::string* err);
 
 // ---- 3x3/s2/p1 max pool NHWC (pool.hip) -----------------------------------------------------
 int launch_maxpool(const float* in, float* out, int nimg, int H, int W, int C, int Ho, int Wo, hipStream_t st);

@@ -150,8 +150,6 @@ struct actmi_ctx {
     float ip_a_scale = 1.f;            // the same for input_proj's operand (the layer4 maps)
     float* act_scale_dev = nullptr;    // device copies [convs.size() + 1] for the kernels that take a device scale (conv3.hip)
     bool fuse_ds = true;               // downsample branch inside conv2's contraction (ACTMI_FUSE_DS=0: three launches as before)
-    bool conv_direct = false;          // layer2-4 stride-1 3x3 convolutions on the direct kernel (conv3g.hip): measured slower, opt-in
-    int conv_direct_min_images = 8;    // below this many images (cameras x batch) its grid is too small: implicit GEMM + split-K
     int64_t ptotal = 0;
     bool finalized = false;
     // geometry

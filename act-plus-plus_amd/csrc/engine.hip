@@ -544,14 +544,7 @@ int engine_create(const actmi_config* cfg, actmi_ctx** out) {
         // contractions are being split (the side branch would share the slice workspace)
         const char* e = getenv("ACTMI_DS_FORK");
         ctx->ds_fork = !(e && e[0] == '0');
-        // layer2-4 stride-1 convolutions on the direct kernel of conv3g.hip: built, bit-checked and measured SLOWER than the
-        // implicit GEMM at 128-512 channels (B = 8: 187 / 203 / 251 us against 173 / 188 / 214 us per launch,
-        // profiles/r02_conv_direct_ab.json): re-staging the patch for every 64-channel chunk costs as much as the chunk's
-        // nine taps of MFMAs.  Off unless ACTMI_CONV_DIRECT=1.
         { const char* ef = getenv("ACTMI_FUSE_DS"); ctx->fuse_ds = !(ef && ef[0] == '0'); }
-        const char* e3 = getenv("ACTMI_CONV_DIRECT");
-        ctx->conv_direct = e3 && e3[0] == '1';
-        if (const char* e4 = getenv("ACTMI_CONV_DIRECT_MIN_IMAGES")) ctx->conv_direct_min_images = atoi(e4);
         if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -636,8 +629,8 @@ int engine_prepare_weights(actmi_ctx* ctx, hipStream_t st, bool after_step) {
         static const bool tap_inner_on = !(getenv("ACTMI_K_TAP_INNER") && getenv("ACTMI_K_TAP_INNER")[0] == '0');
         for (ConvLayer& cl : ctx->convs) {
             // K order of the image: channel blocks outer, taps inner, for the convolutions of the implicit-GEMM kernel (L2 reuse of
-            // the input patch); the direct kernels of layer1 (and the opt-in conv3g) read (r, s, c)
-            const bool direct = cl.k == 3 && cl.stride == 1 && cl.pad == 1 && ((cl.cin == 64 && cl.cout == 64) || ctx->conv_direct);
+            // the input patch); the direct kernel of layer1 reads (r, s, c)
+            const bool direct = cl.k == 3 && cl.stride == 1 && cl.pad == 1 && cl.cin == 64 && cl.cout == 64;
             cl.k_tap_inner = tap_inner_on && cl.k == 3 && (cl.cin % 32) == 0 && !direct &&
                              (int64_t)C * cl.cout * (cl.K + cl.Kx) <= ctx->splitk_ws_floats;
             if (cl.k_tap_inner) {
@@ -913,15 +906,6 @@ int engine_backbone(actmi_ctx* ctx, const void* image, int fmt, int B, hipStream
             c3.G = nc; c3.B = B; c3.H = cl.H; c3.W = cl.W; c3.relu = relu; c3.w_scale = cl.w16_scale;
             if (cl.a_scale != 1.f) c3.x_scale_dev = ctx->act_scale_dev + cl_index;
             return launch_conv3x3_c64(c3, cs, &ctx->err);
-        }
-        if (ctx->gemm_prec == ACTMI_PREC_F16X3 && ctx->conv_direct && cl.k == 3 && cl.stride == 1 && cl.pad == 1 &&
-            (cl.cin % 64) == 0 && (cl.cout % 64) == 0 && B * C >= ctx->conv_direct_min_images && cl.a_scale == 1.f) {
-            // layer2-4 stride-1 convolutions: the same direct scheme per 64-channel chunk (conv3g.hip) -- a third fewer
-            // operand bytes per MFMA than the implicit GEMM at its 128x128 tile
-            Conv3gArgs cg;
-            cg.x = in; cg.w16 = cl.w16 + c0 * w_cam; cg.scale = scale; cg.bias = bias; cg.res = res; cg.out = out;
-            cg.G = nc; cg.B = B; cg.H = cl.H; cg.W = cl.W; cg.Cin = cl.cin; cg.Cout = cl.cout; cg.relu = relu; cg.w_scale = cl.w16_scale;
-            return launch_conv3x3_direct(cg, cs, &ctx->err);
         }
         GemmArgs a;
         memset(&a, 0, sizeof(a));

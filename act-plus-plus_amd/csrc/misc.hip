@@ -338,50 +338,6 @@ int launch_check_finite(const float* x, int64_t n, uint32_t* flag, uint32_t bit,
     return (int)hipGetLastError();
 }
 
-// "s16" form of a row-major fp32 tensor (gemm16.hip): every aligned group of 8 floats -> [8 hi halfs][8 lo halfs] of
-// (x * scale) in the same 32 bytes.  unsplit: x = (hi + lo) / scale, exact to the split's 22-23 significand bits.
-__global__ void split16v2_kernel(const actmi_f32x4* __restrict__ src, uint4* __restrict__ dst, int64_t n8, float scale) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n8) return;
-    uint2 h0, l0, h1, l1;
-    split16(src[2 * i] * scale, h0, l0);
-    split16(src[2 * i + 1] * scale, h1, l1);
-    dst[2 * i] = uint4{h0.x, h0.y, h1.x, h1.y};
-    dst[2 * i + 1] = uint4{l0.x, l0.y, l1.x, l1.y};
-}
-
-typedef _Float16 misc_h16x8 __attribute__((ext_vector_type(8)));
-__global__ void unsplit16v2_kernel(const uint4* __restrict__ src, actmi_f32x4* __restrict__ dst, int64_t n8, float inv_scale) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n8) return;
-    const misc_h16x8 h = __builtin_bit_cast(misc_h16x8, src[2 * i]), l = __builtin_bit_cast(misc_h16x8, src[2 * i + 1]);
-    actmi_f32x4 a, b;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        a[e] = ((float)h[e] + (float)l[e]) * inv_scale;
-        b[e] = ((float)h[4 + e] + (float)l[4 + e]) * inv_scale;
-    }
-    dst[2 * i] = a;
-    dst[2 * i + 1] = b;
-}
-
-int launch_split16v2(const float* src, void* dst, int64_t nfloats, float scale, hipStream_t st) {
-    if (nfloats <= 0) return 0;
-    if ((nfloats & 7) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return -2;
-    const int64_t n8 = nfloats / 8;
-    hipLaunchKernelGGL(split16v2_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<const actmi_f32x4*>(src), reinterpret_cast<uint4*>(dst), n8, scale);
-    return (int)hipGetLastError();
-}
-
-int launch_unsplit16v2(const void* src, float* dst, int64_t nfloats, float scale, hipStream_t st) {
-    if (nfloats <= 0) return 0;
-    if ((nfloats & 7) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15) || !(scale > 0.f)) return -2;
-    const int64_t n8 = nfloats / 8;
-    hipLaunchKernelGGL(unsplit16v2_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<const uint4*>(src), reinterpret_cast<actmi_f32x4*>(dst), n8, 1.0f / scale);
-    return (int)hipGetLastError();
-}
 
 __global__ void scale_kernel(float* __restrict__ x, int64_t n4, int64_t n, float s) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

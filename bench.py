@@ -63,10 +63,10 @@ GFLOP_TRAIN_PER_SAMPLE_LIVE = 447.0      # fwd 149 incl. CVAE + bwd
 
 
 def kernel_peak(name):
-    """Dense MFMA peak, in ALGORITHMIC fp32 FLOP/s, of the arithmetic a kernel uses.  *_f16x3 / *16 kernels form every fp32
+    """Dense MFMA peak, in ALGORITHMIC fp32 FLOP/s, of the arithmetic a kernel uses.  *_f16x3 kernels form every fp32
     product from three fp16 MFMA products (exact two-piece fp16 split of both operands), so their ceiling is a third of
     the fp16 matrix peak; everything else runs the native fp32 MFMA."""
-    if "f16x3" in name or name.startswith("gemm16"):
+    if "f16x3" in name:
         return PEAK_FP16_MATRIX_TFLOPS / 3.0, "f16 MFMA dense peak / 3 products per fp32 product"
     if "bf16" in name:
         return PEAK_FP16_MATRIX_TFLOPS, "bf16 MFMA dense peak (one product per fp32 product)"

@@ -182,47 +182,6 @@ typedef struct actmi_gemm_desc {
     int32_t k_tap_inner;
 } actmi_gemm_desc;
 
-/* GEMM / implicit-GEMM convolution on PRE-SPLIT operands (the inference path's form of actmi_gemm_desc with prec f16x3;
- * same reference call sites: nn.Linear / MHA projections transformer.py:196-224, input_proj detr_vae.py:184, torchvision
- * Conv2d + FrozenBatchNorm2d backbone.py:47-57).  "s16" tensors hold, for every aligned group of 8 consecutive elements
- * of a row, 32 bytes = [8 fp16 hi pieces][8 fp16 lo pieces] of (x * tensor scale): the byte size, strides and addressing
- * are those of the fp32 tensor (all ld / group strides below are in ELEMENTS, 4 bytes each), see actmi_op_split16v2.
- * C[rowmap(m)][n] = act((sum_k A[m][k] * Bw[n][k]) * alpha * scale[n] + bias[n] + residual[m or m % res_mod][n]) */
-typedef struct actmi_gemm16_desc {
-    const void* A;             /* s16: rows [M][K] (mode 0) or NHWC images [img][H][W][Cin] (mode 1) */
-    int64_t lda;
-    int32_t mode;              /* 0 rows, 1 NHWC implicit im2col (K index = (r*KW+s)*Cin + c, Cin % 32 == 0) */
-    int32_t H, W, Cin, KH, KW, stride, pad, Ho, Wo;
-    int64_t img_stride;
-    const void* Bw;            /* s16 [N][K] (torch Linear layout / [cout][(r,s,c)]) */
-    int64_t ldb;
-    float alpha;               /* undoes the operand scales: 1 / (scale of A * scale of Bw); 0 means 1 */
-    const float* scale;        /* per-n or NULL (FrozenBN) */
-    const float* bias;         /* per-n or NULL */
-    const void* res;           /* residual or NULL */
-    int64_t ldres;
-    int32_t res_fmt;           /* 0: f32 rows, 1: s16 rows (value = (hi + lo) * res_scale) */
-    int32_t res_mod;           /* >0: residual row = m % res_mod (a table shared by the batch) */
-    float res_scale;           /* 1 / (scale of the s16 residual); 0 means 1 */
-    int32_t relu;
-    void* C;
-    int64_t ldc;
-    int32_t c_fmt;             /* 0: f32 rows, 1: s16 rows of (value * c_scale) */
-    float c_scale;             /* 0 means 1 */
-    const int32_t* rowmap;     /* optional scatter of output rows */
-    int32_t M, N, K;           /* K % 32 == 0, N % 8 == 0 */
-    int32_t groups;
-    int64_t gA, gB, gSB, gC, gRes;
-    int32_t splitk;            /* >1: contraction split over the grid into plain f32 slices at C + s*split_stride */
-    int64_t split_stride;
-    const void* zero_page;     /* mode 1: >= 128 bytes of zeros (padding taps read it) */
-    uint32_t* flag;            /* optional: bit 0 is set when an s16 output value is not finite or leaves the fp16 range */
-    int32_t bm;                /* tile rows: 0 = choose, 128 or 256 */
-    /* diagnostic, never set on the product path: thread 0 of workgroup 0 writes shader-clock stamps (s_memtime) here:
-     * [0] entry, [1] first step landed, then per tile [2+2i] K loop done, [3+2i] epilogue done; [63] = s_memrealtime span */
-    uint64_t* stamps;
-} actmi_gemm16_desc;
-
 /* Multi-head attention descriptor: softmax(scale * q k^T [+ key padding mask]) v per (batch, head).
  * Replaces nn.MultiheadAttention's bmm/softmax/bmm (transformer.py:217-218, 282-289). */
 typedef struct actmi_attn_desc {
@@ -328,12 +287,6 @@ int actmi_op_split16(const float* src, float* dst, int64_t nfloats, float scale,
 /* rows [rows][ld] of a convolution weight matrix: the first taps*cin columns re-ordered from (tap, c) to (c / 32, tap, c % 32)
  * (actmi_gemm_desc.k_tap_inner), any further columns (ld > taps*cin: a second source's) copied as they are; cin % 32 == 0 */
 int actmi_op_permute_conv_k(const float* src, float* dst, int64_t rows, int taps, int cin, int ld, void* stream);
-/* s16 form of a row-major f32 tensor (actmi_gemm16_desc): dst = split of (src * scale), nfloats % 8 == 0, device pointers
- * that may not alias; scale a power of two with |src| * scale < 65504.  actmi_op_unsplit16v2 is the inverse
- * (dst = (hi + lo) / scale: exact to the 22-23 significand bits the split keeps). */
-int actmi_op_split16v2(const float* src, void* dst, int64_t nfloats, float scale, void* stream);
-int actmi_op_unsplit16v2(const void* src, float* dst, int64_t nfloats, float scale, void* stream);
-int actmi_op_gemm16(const actmi_gemm16_desc* d, void* stream);
 /* out[0] = the power of two s with max|x| * s in [2^13, 2^14) over the M x N matrix x (row stride ld); 1 if x is all
  * zero or not finite.  out[1] is scratch and must be zero before the first use (the op leaves it zero).  For actmi_gemm_desc.a_scale_dev / b_scale_dev. */
 int actmi_op_pow2_scale(const float* x, int64_t ld, int M, int N, float* out, void* stream);
@@ -369,12 +322,6 @@ int actmi_op_conv1_prepared(const void* image_u8, const float* workspace, const 
  * out = act(conv * scale + bias (+ res)) */
 int actmi_op_conv3x3_c64(const float* x, const float* w16, float w_scale, const float* scale, const float* bias,
                          const float* res, float* out, int G, int B, int H, int W, int relu, void* stream);
-/* the same scheme for Cin, Cout multiples of 64 (ResNet18 layer2-4 stride-1 convolutions): x [G][B][H][W][Cin], w16 =
- * actmi_op_split16 image of [G][Cout][3][3][Cin], per 64-channel chunk an LDS-resident patch, wave blocks of 1x32 / 2x16 / 4x8
- * output pixels chosen by the map width */
-int actmi_op_conv3x3_direct(const float* x, const float* w16, float w_scale, const float* scale, const float* bias,
-                            const float* res, float* out, int G, int B, int H, int W, int Cin, int Cout, int relu, void* stream);
-
 /* weight gradient of the same 64 -> 64 channel 3x3 / s1 / p1 convolution (training path; torch.autograd of F.conv2d in
  * torchvision's BasicBlock, reference backbone.py:95-134), f16x3 arithmetic: dw[G][64][(r,s,ci)] = sum over images and pixels of
  * dy[G][B][H][W][64] x x[G][B][H][W][64] shifted by the tap.  ws: workspace of >= G * 64 * 576 * min(256 / G, B * ceil(W/32))

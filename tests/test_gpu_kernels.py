@@ -371,26 +371,6 @@ def test_ensemble_with_no_populated_row_is_the_reference_empty_sum():
     assert n_empty == 3
 
 
-@pytest.mark.parametrize("G,B,H,W,Cin,Cout", [(2, 2, 60, 80, 128, 128), (2, 3, 30, 40, 256, 256), (1, 2, 15, 20, 512, 512),
-                                             (1, 1, 9, 37, 64, 128), (2, 1, 17, 5, 128, 64)])
-def test_conv3x3_direct_matches_torch(G, B, H, W, Cin, Cout):
-    """layer2-4 stride-1 convolutions on the direct kernel (LDS-resident patch per 64-channel chunk; wave blocks 1x32 / 2x16 /
-    4x8 by map width), with FrozenBN affine, residual and ReLU; vs torch conv2d in fp64."""
-    g = torch.Generator().manual_seed(Cin + Cout + H)
-    x = torch.randn(G, B, H, W, Cin, generator=g)
-    w = torch.randn(G, Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5
-    sc, bi = torch.rand(G, Cout, generator=g) + 0.5, torch.randn(G, Cout, generator=g)
-    res = torch.randn(G, B, H, W, Cout, generator=g)
-    got = ops.conv3x3_direct(x.to(dev()), w.to(dev()), sc.to(dev()), bi.to(dev()), res=res.to(dev()), relu=True).cpu()
-    for c in range(G):
-        y = F.conv2d(x[c].permute(0, 3, 1, 2).double(), w[c].permute(0, 3, 1, 2).double(), padding=1)
-        y = y * sc[c].double().view(1, -1, 1, 1) + bi[c].double().view(1, -1, 1, 1)
-        exp = F.relu(y.permute(0, 2, 3, 1) + res[c].double())
-        assert rel_err(got[c], exp) < 2e-6
-    plain = ops.conv3x3_direct(x.to(dev()), w.to(dev()), sc.to(dev()), bi.to(dev())).cpu()
-    assert torch.equal(plain, ops.conv3x3_direct(x.to(dev()), w.to(dev()), sc.to(dev()), bi.to(dev())).cpu())
-
-
 @pytest.mark.parametrize("G,B,H,W", [(1, 1, 6, 32), (2, 3, 9, 37), (4, 2, 30, 40), (1, 2, 5, 70), (3, 1, 1, 1)])
 def test_wgrad3x3_c64_matches_torch(G, B, H, W):
     """weight gradient of the layer1 convolutions on the direct kernel (strip walk, transposed staging, nine taps per staged
