@@ -9,6 +9,8 @@ import ctypes as C
 import os
 
 import numpy as np
+import time
+
 import torch
 
 from . import lib as L
@@ -187,7 +189,11 @@ class ACTEngine:
                                      "(ACTMI_GEMM_PREC=f32)")
         return out
 
-    def capture_infer(self, batch: int, image_dtype=torch.uint8, with_ensemble=None):
+    def set_forward_phase(self, phase: int):
+        """0: forward_infer runs the whole step; 1: trunk + token assembly only; 2: transformer only (actmi_set_forward_phase)"""
+        L.check(self.lib.actmi_set_forward_phase(self.h, int(phase)), self.h, "set_forward_phase")
+
+    def capture_infer(self, batch: int, image_dtype=torch.uint8, with_ensemble=None, statics=None, phase: int = 0):
         """Capture one forward (optionally + the temporal-ensemble kernel) into a hipGraph and return
         ``replay(qpos, image) -> a_hat`` that copies into static inputs and replays.  The forward path allocates
         nothing and never synchronises, so the whole step is one graph launch (removes ~60 kernel-launch gaps; matters
@@ -197,9 +203,12 @@ class ACTEngine:
         cfg, dev = self.cfg, self.device
         shape = (batch, cfg.num_cams, cfg.image_h, cfg.image_w, 3) if image_dtype == torch.uint8 else \
                 (batch, cfg.num_cams, 3, cfg.image_h, cfg.image_w)
-        s_qpos = torch.zeros((batch, cfg.state_dim), dtype=torch.float32, device=dev)
-        s_img = torch.zeros(shape, dtype=image_dtype, device=dev)
-        s_out = torch.empty((batch, cfg.num_queries, cfg.action_dim), dtype=torch.float32, device=dev)
+        if statics is not None:
+            s_qpos, s_img, s_out = statics
+        else:
+            s_qpos = torch.zeros((batch, cfg.state_dim), dtype=torch.float32, device=dev)
+            s_img = torch.zeros(shape, dtype=image_dtype, device=dev)
+            s_out = torch.empty((batch, cfg.num_queries, cfg.action_dim), dtype=torch.float32, device=dev)
         # warm-up on a side stream (first launches set function attributes; not allowed during capture)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -213,10 +222,16 @@ class ACTEngine:
         if with_ensemble is not None:
             with_ensemble.reset()
         graph = torch.cuda.CUDAGraph()
-        # thread_local: calls made by other threads (e.g. the RCCL watchdog of a multi-rank bench) must not void the capture
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            self.forward_infer(s_qpos, s_img, out=s_out)
-            ens_out = with_ensemble.step(s_out) if with_ensemble is not None else None
+        ens_out = None
+        self.set_forward_phase(phase)          # (InferPipeline: the trunk and the transformer as graphs of their own)
+        try:
+            # thread_local: calls made by other threads (e.g. the RCCL watchdog of a multi-rank bench) must not void the capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                self.forward_infer(s_qpos, s_img, out=s_out)
+                if with_ensemble is not None and phase != 1:
+                    ens_out = with_ensemble.step(s_out)
+        finally:
+            self.set_forward_phase(0)
         if with_ensemble is not None:
             with_ensemble.reset()               # the capture itself does not execute, but keep the state explicit
 
@@ -520,60 +535,112 @@ class ACTEngine:
 
 
 class InferPipeline:
-    """Double-buffered policy queries fed from the HOST: two captured graphs of the step (forward [+ temporal ensemble]) over
-    two sets of static input buffers.  While the graph of step t runs out of buffer t % 2, the frames of step t + 1 cross PCIe
-    into buffer (t + 1) % 2 on a copy stream of their own, so a rollout loop that knows its next frames early (camera capture
-    running ahead of the policy, replayed episodes, the benchmark's with_h2d leg) pays max(copy, step) per step instead of
-    copy + step (the 29.5 MB pinned copy used to sit in front of every graph launch).
+    """Double-buffered policy queries fed from the HOST: the copy of frame t + 1 runs beside the TRANSFORMER of step t.
+
+    Two sets of device input buffers ("slots"), each with two captured graphs: the trunk (the only reader of the frame, and the
+    HBM-bound part of the step) and the transformer + ensemble (actmi_set_forward_phase).  Between the two graphs of step t the
+    stream records an ordinary event; the copy stream waits for it, copies the next frame into the OTHER slot and records
+    `ev_copy`, which the trunk graph of step t + 1 waits for.  The 29.5 MB copy (0.53 ms alone) thereby overlaps the compute-bound
+    transformer: released beside the START of the step -- the stem -- it slowed the step by 0.33-0.37 ms (tools/h2d_probe.py),
+    and as a memcpy node inside one whole-step graph it did not overlap at all (+0.52 ms, profiles/r03_h2d_probe.json).
+    A rollout loop that knows its next frame one step early (cameras running ahead of the policy, replayed episodes, the
+    benchmark's with_h2d leg) pays ~max(copy, step) instead of copy + step.
 
         pipe = InferPipeline(engine, batch, with_ensemble=ens)
-        pipe.feed(qpos0, frames0)
+        pipe.feed(qpos_host[0], frames_host[0])            # pinned host tensors
         for t in range(T):
-            if t + 1 < T: pipe.feed(qpos[t + 1], frames[t + 1])     # host (pinned) or device tensors; returns at once
-            a_hat, raw = pipe.step()                                # outputs of step t (device tensors of buffer t % 2)
+            a_hat, raw = pipe.step(next_inputs=(qpos_host[t + 1], frames_host[t + 1]) if t + 1 < T else None)
 
-    Ordering is by events only (no host synchronisation): a copy into a buffer waits for the graph that last read it, a
-    graph waits for the copy that filled its buffer.  Outputs of step t stay valid until step t + 2 is issued."""
+    No host synchronisation anywhere; the pinned host tensors of a feed must stay untouched until the step AFTER the one they were
+    passed to has been issued and `pipe.copied(k)` has completed (or simply use one host buffer per step in flight).  Outputs of
+    step t stay valid until step t + 2 is issued."""
 
-    def __init__(self, engine: "ACTEngine", batch: int, with_ensemble=None, image_dtype=torch.uint8):
+    def __init__(self, engine: "ACTEngine", batch: int, with_ensemble=None, image_dtype=torch.uint8, copy_stream_candidates: int = 8):
         self.engine, self.dev = engine, engine.device
-        self.slots = [engine.capture_infer(batch, image_dtype=image_dtype, with_ensemble=with_ensemble) for _ in range(2)]
-        self.copy_stream = torch.cuda.Stream(device=self.dev)
-        self.ev_copy = [torch.cuda.Event() for _ in range(2)]
-        self.ev_done = [torch.cuda.Event() for _ in range(2)]
-        self.used = [False, False]
-        self.k_feed = self.k_run = 0
-        self.pending = 0
+        cfg, dev = engine.cfg, engine.device
+        shape = (batch, cfg.num_cams, cfg.image_h, cfg.image_w, 3) if image_dtype == torch.uint8 else \
+                (batch, cfg.num_cams, 3, cfg.image_h, cfg.image_w)
+        self.slots = []
+        for _ in range(2):
+            st = (torch.zeros((batch, cfg.state_dim), dtype=torch.float32, device=dev), torch.zeros(shape, dtype=image_dtype, device=dev),
+                  torch.empty((batch, cfg.num_queries, cfg.action_dim), dtype=torch.float32, device=dev))
+            trunk = engine.capture_infer(batch, image_dtype=image_dtype, statics=st, phase=1)
+            rest = engine.capture_infer(batch, image_dtype=image_dtype, with_ensemble=with_ensemble, statics=st, phase=2)
+            self.slots.append((st, trunk, rest))
+        self.ev_copy = [torch.cuda.Event() for _ in range(2)]       # slot k's inputs have landed
+        self.ev_trunk = [torch.cuda.Event() for _ in range(2)]      # slot k's trunk has run: its inputs are dead
+        self.fed = [False, False]
+        self.ran = [False, False]
+        self.k_run = 0
+        self.copy_stream, self.copy_stream_trials = self._pick_copy_stream(max(1, int(copy_stream_candidates)), with_ensemble)
 
-    def feed(self, qpos, image):
-        if self.pending >= 2:
-            raise RuntimeError("InferPipeline.feed: both buffers hold unconsumed inputs (call step() first)")
-        k = self.k_feed
-        s_qpos, s_img, _ = self.slots[k].static
+    def _pick_copy_stream(self, n_cand, ens):
+        """HIP maps its streams onto a few hardware queues (4 by default), in order of creation.  The barrier packet behind an
+        SDMA copy (the event record that publishes it) holds up whatever shares the copy stream's queue: measured, one of the
+        transformer's two branches sat out the whole 0.56 ms copy (profiles/r03_h2d_timeline.txt), and a high-priority copy
+        stream slowed every kernel of the step instead.  Which queue a stream lands on is not visible through the API, so the
+        pipeline times a few steps over each of `n_cand` consecutive streams and keeps the one that does not collide."""
+        dev = self.dev
+        if n_cand == 1:
+            return torch.cuda.Stream(device=dev), []
+        (q0, im0, _), _, _ = self.slots[0]
+        hq, him = torch.zeros(q0.shape, dtype=q0.dtype).pin_memory(), torch.zeros(im0.shape, dtype=im0.dtype).pin_memory()
+        trials = []
+        for _ in range(n_cand):
+            self.copy_stream = cs = torch.cuda.Stream(device=dev)
+            dt = []
+            for rep in range(2):                                    # (the first round also warms the graphs up)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                self.feed(hq, him)
+                for i in range(6):
+                    self.step(next_inputs=(hq, him) if i < 5 else None)
+                torch.cuda.synchronize(dev)
+                dt.append((time.perf_counter() - t0) / 6)
+            trials.append((dt[1], cs))
+        self.fed, self.ran, self.k_run = [False, False], [False, False], 0
+        if ens is not None:
+            ens.reset()
+        best = min(trials, key=lambda t: t[0])
+        return best[1], [round(t[0] * 1e3, 4) for t in trials]
+
+    def feed(self, qpos_host, image_host, slot=None):
+        """enqueue the copy of one step's inputs (pinned host tensors) into slot `slot` (default: the slot the next step() runs
+        from); it starts once the trunk that read the slot last has run AND the step in flight has left its own trunk"""
+        k = self.k_run if slot is None else slot
+        s_qpos, s_img, _ = self.slots[k][0]
         cs = self.copy_stream
-        if self.used[k]:
-            cs.wait_event(self.ev_done[k])                 # the graph that last read this buffer has finished
-        else:
-            cs.wait_stream(torch.cuda.current_stream(self.dev))
+        if self.ran[k]:
+            cs.wait_event(self.ev_trunk[k])
+        if self.ran[k ^ 1]:
+            cs.wait_event(self.ev_trunk[k ^ 1])                     # the step in flight: copy beside its transformer, not its stem
         with torch.cuda.stream(cs):
-            s_img.copy_(image, non_blocking=True)
-            s_qpos.copy_(qpos, non_blocking=True)
+            s_qpos.copy_(qpos_host, non_blocking=True)
+            s_img.copy_(image_host, non_blocking=True)
             self.ev_copy[k].record(cs)
-        self.k_feed ^= 1
-        self.pending += 1
+        self.fed[k] = True
 
-    def step(self):
-        if self.pending < 1:
-            raise RuntimeError("InferPipeline.step without a fed input")
+    def copied(self, k: int):
+        """block until the last feed into slot k has landed (its host tensors may be rewritten)"""
+        self.ev_copy[k].synchronize()
+
+    def step(self, next_inputs=None):
+        """run one step from the current slot; `next_inputs` = (qpos_host, image_host) of the FOLLOWING step, copied into the
+        other slot beside this step's transformer"""
         k = self.k_run
+        if not self.fed[k]:
+            raise RuntimeError("InferPipeline.step: no inputs were fed for this step")
+        (s_qpos, s_img, _), trunk, rest = self.slots[k]
         cur = torch.cuda.current_stream(self.dev)
         cur.wait_event(self.ev_copy[k])
-        s_qpos, s_img, _ = self.slots[k].static
-        out = self.slots[k](s_qpos, s_img)                 # graph launch alone: the inputs already sit in its static buffers
-        self.ev_done[k].record(cur)
-        self.used[k] = True
+        trunk(s_qpos, s_img)
+        self.ev_trunk[k].record(cur)
+        self.ran[k] = True
+        self.fed[k] = False
+        if next_inputs is not None:
+            self.feed(next_inputs[0], next_inputs[1], slot=k ^ 1)
+        out = rest(s_qpos, s_img)
         self.k_run ^= 1
-        self.pending -= 1
         return out
 
 

@@ -93,6 +93,7 @@ def load():
         "actmi_get_param": ([vp, C.c_char_p, vp, i64, i32], i32),
         "actmi_param_ptr": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i64)], i32),
         "actmi_finalize": ([vp, vp], i32),
+        "actmi_set_forward_phase": ([vp, i32], i32),
         "actmi_forward_infer_vq": ([vp, vp, vp, i32, i32, vp, vp, vp], i32),
         "actmi_forward_infer": ([vp, vp, vp, i32, i32, vp, vp], i32),
         "actmi_forward_train": ([vp, vp, vp, i32, vp, vp, vp, C.c_uint64, f32, i32, vp, vp, vp, vp, vp], i32),

@@ -113,6 +113,13 @@ int actmi_forward_infer(actmi_handle h, const float* qpos, const void* image, in
     return engine_forward_infer(h, qpos, image, image_fmt, B, a_hat, S(stream), nullptr);
 }
 
+int actmi_set_forward_phase(actmi_handle h, int phase) {
+    if (!h) return ACTMI_E_INVALID;
+    if (phase < 0 || phase > 2) { h->err = "forward phase must be 0 (whole), 1 (trunk) or 2 (transformer)"; return ACTMI_E_INVALID; }
+    h->fwd_phase = phase;
+    return ACTMI_OK;
+}
+
 int actmi_forward_infer_vq(actmi_handle h, const float* qpos, const void* image, int image_fmt, int B,
                            const float* vq_sample, float* a_hat, void* stream) {
     if (!h) return ACTMI_E_INVALID;

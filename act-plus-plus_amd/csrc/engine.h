@@ -114,6 +114,7 @@ struct actmi_ctx {
     int train_prec = 0;                // ACTMI_PREC_BF16: the GEMMs of the TRAINING step form one bf16 product per fp32 product
                                        // (opt-in speed mode, actmi_set_train_prec / ACTMI_TRAIN_PREC=bf16); 0 = gemm_prec
     int prec_override = 0;             // set for the duration of train_forward / train_backward (PrecScope)
+    int fwd_phase = 0;                 // actmi_set_forward_phase: 0 whole inference forward, 1 trunk + token assembly only, 2 transformer only
     // range guard of the f16x3 forward: one power-of-two scale per parameter for its split image, chosen at
     // finalize so that max|w| * scale lands in [2^13, 2^14) (capped at 2^12); device copies for the split kernel
     std::vector<float> pscale;         // per parameter (index = position in params)

@@ -1166,25 +1166,33 @@ int engine_forward_infer(actmi_ctx* ctx, const float* qpos, const void* image, i
     if (fmt != ACTMI_IMG_U8_NHWC && fmt != ACTMI_IMG_F32_NCHW) { ctx->err = "bad image format"; return ACTMI_E_INVALID; }
     const actmi_config& g = ctx->cfg;
     const int D = g.hidden_dim, N = ctx->N;
-    {
+    // actmi_set_forward_phase: the step as two halves a caller can capture into two graphs -- the trunk with the token assembly
+    // (the only reader of `image` and `qpos`, and the HBM-heavy part) and the transformer -- so that the host-to-device copy of the
+    // NEXT frame hangs on an ordinary stream event between them and runs beside the transformer.  Phase 2 continues from the tokens
+    // phase 1 left in ctx->X.
+    if (ctx->fwd_phase != 2) {
         const int rc = engine_backbone(ctx, image, fmt, B, st);
         if (rc == 1) return 0;
         if (rc != 0) return rc;
+        // token 0: latent_input = latent_out_proj(0) = bias (detr_vae.py:158-159), or latent_out_proj(code) for VQ-ACT
+        // (detr_vae.py:155-156); token 1: proprio (detr_vae.py:213)
+        float* fill_dst = nullptr;
+        if (g.vq && vq_sample) {
+            const int K = g.vq_class * g.vq_dim;
+            GemmArgs lz = linear_args(vq_sample, K, B, K, ctx->P("latent_out_proj.weight"), D, ctx->P("latent_out_proj.bias"),
+                                      ctx->X, (int64_t)N * D);
+            CHK(ctx_gemm(ctx, lz, st));
+        } else {
+            fill_dst = ctx->X;                   // token 0 = the bias row, written by the proprio projection's launch
+        }
+        CHK(launch_small_linear(qpos, g.state_dim, ctx->P("input_proj_robot_state.weight"),
+                                ctx->P("input_proj_robot_state.bias"), ctx->X + D, (int64_t)N * D, B, D, g.state_dim, st, fill_dst,
+                                ctx->P("latent_out_proj.bias"), 0));
+        if (ctx->fwd_phase == 1) { ctx->last_B = B; return 0; }
+    } else if (B != ctx->last_B) {
+        ctx->err = "forward phase 2 without a phase 1 of the same batch before it";
+        return ACTMI_E_STATE;
     }
-    // token 0: latent_input = latent_out_proj(0) = bias (detr_vae.py:158-159), or latent_out_proj(code) for VQ-ACT
-    // (detr_vae.py:155-156); token 1: proprio (detr_vae.py:213)
-    float* fill_dst = nullptr;
-    if (g.vq && vq_sample) {
-        const int K = g.vq_class * g.vq_dim;
-        GemmArgs lz = linear_args(vq_sample, K, B, K, ctx->P("latent_out_proj.weight"), D, ctx->P("latent_out_proj.bias"),
-                                  ctx->X, (int64_t)N * D);
-        CHK(ctx_gemm(ctx, lz, st));
-    } else {
-        fill_dst = ctx->X;                       // token 0 = the bias row, written by the proprio projection's launch
-    }
-    CHK(launch_small_linear(qpos, g.state_dim, ctx->P("input_proj_robot_state.weight"),
-                            ctx->P("input_proj_robot_state.bias"), ctx->X + D, (int64_t)N * D, B, D, g.state_dim, st, fill_dst,
-                            ctx->P("latent_out_proj.bias"), 0));
     ctx->dbg["src"] = {ctx->X, (int64_t)B * N * D};
     if (ctx->stop_stage == "src") return 0;
     ctx->last_B = B;

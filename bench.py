@@ -228,11 +228,11 @@ class InferRig:
         self.replay, self.pipe = None, None
         if graph:
             try:
-                # forward + ensemble as ONE graph launch; two graphs over two input buffers (engine.InferPipeline) so that the
-                # with_h2d leg can copy the next step's frames while this step runs.  The headline leg replays buffer 0 only.
+                # forward + ensemble as ONE graph launch.  The with_h2d leg uses engine.InferPipeline instead: two input buffers,
+                # the step as a trunk graph and a transformer graph, the H2D copy of the NEXT step's frames beside the latter.
                 from actmi.engine import InferPipeline
+                self.replay = self.eng.capture_infer(B, with_ensemble=self.ens)
                 self.pipe = InferPipeline(self.eng, B, with_ensemble=self.ens)
-                self.replay = self.pipe.slots[0]
             except Exception as e:                               # capture unsupported -> eager launches
                 log(f"hipGraph capture failed ({e}); falling back to eager launches")
                 self.replay, self.pipe = None, None
@@ -274,13 +274,11 @@ class InferRig:
             self.step()
         sync()
         if with_h2d and self.pipe is not None:
-            pipe = self.pipe
+            pipe, nxt = self.pipe, (self.qpos_host, self.image_host)
             t0 = time.perf_counter()
-            pipe.feed(self.qpos_host, self.image_host)
+            pipe.feed(*nxt)
             for i in range(steps):
-                if i + 1 < steps:
-                    pipe.feed(self.qpos_host, self.image_host)
-                pipe.step()
+                pipe.step(next_inputs=nxt if i + 1 < steps else None)   # trunk graph, event, copy of the next frame, transformer graph
             sync()
             return time.perf_counter() - t0
         t0 = time.perf_counter()
@@ -476,8 +474,8 @@ def bench_infer(args, cfg, B, ctx):
         "with_h2d": {"ms_per_step": h2d_dt / args.steps * 1e3, "value": B * args.steps / h2d_dt, "unit": "policy steps/s",
                      "h2d_bytes_per_step": int(rig.image_host.numel()),
                      "note": "fresh u8 frames (and qpos) copied from pinned host memory every step, double-buffered: the copy "
-                             "of step t+1 runs on a copy stream beside the graph of step t (engine.InferPipeline); rank 0 only; "
-                             "not the headline"},
+                             "of step t+1 runs on a copy stream beside the transformer of step t, released by an event between the step's trunk graph and its transformer graph (engine.InferPipeline); "
+                             "rank 0 only; not the headline"},
         "kernels": kernels,
         "step_latency_ms": lat,
         "ranks_seen": ranks_seen,

@@ -232,6 +232,14 @@ int actmi_finalize(actmi_handle h, void* stream);
 int actmi_forward_infer(actmi_handle h, const float* qpos /*[B][S]*/, const void* image, int image_fmt, int B,
                         float* a_hat /*[B][Q][A]*/, void* stream);
 
+/* The inference forward in two halves, for callers that feed frames from the host: phase 1 = multi-camera ResNet trunk + token
+ * assembly (the only reader of `image` and `qpos`, and the HBM-heavy part of the step), phase 2 = transformer + action head (reads
+ * the tokens phase 1 left in the handle; `image`, `qpos` are ignored).  actmi_forward_infer runs the selected phase until it is set
+ * back to 0 (whole step, the default).  Captured into two hipGraphs, an ordinary stream event between them releases the
+ * host-to-device copy of the NEXT frame beside the transformer instead of beside the stem (actmi/engine.py:InferPipeline).
+ * The reference has no counterpart (its eval loop copies, then computes: imitate_episodes.py:286-300). */
+int actmi_set_forward_phase(actmi_handle h, int phase);
+
 /* VQ-ACT inference, ACTPolicy.__call__(qpos, image, vq_sample=code) (policy.py:322-332, detr_vae.py:155-156): the latent
  * token is latent_out_proj(vq_sample[b]) instead of latent_out_proj(0).  vq_sample: [B][vq_class*vq_dim] f32 device. */
 int actmi_forward_infer_vq(actmi_handle h, const float* qpos, const void* image, int image_fmt, int B,

@@ -1,4 +1,4 @@
-"""engine.InferPipeline: double-buffered, host-fed policy queries (the copy of step t + 1 beside the graph of step t) must give
+"""engine.InferPipeline: double-buffered, host-fed policy queries (the copy of step t + 1 beside the transformer of step t) must give
 exactly what one-at-a-time eager steps give on the same frames -- actions AND the temporal ensemble's running state."""
 import numpy as np
 import pytest
@@ -27,19 +27,19 @@ def test_pipelined_host_fed_steps_equal_sequential_eager_steps(B):
     for f in frames:
         a = eng.forward_infer(torch.from_numpy(f["qpos"]).to(d), torch.from_numpy(f["image_u8"]).to(d))
         exp.append((a.clone(), ens_e.step(a).clone()))
-    # pipeline: pinned host frames, fed one step ahead
+    # pipeline: pinned host frames; the copy of frame t + 1 is handed over with step t and runs beside its transformer
+    host = [(torch.from_numpy(f["qpos"]).pin_memory(), torch.from_numpy(f["image_u8"]).pin_memory()) for f in frames]
     ens_p = ops.TemporalEnsemble(B, cfg.num_queries, cfg.action_dim, 0.01, d)
     pipe = InferPipeline(eng, B, with_ensemble=ens_p)
-    host = [(torch.from_numpy(f["qpos"]).pin_memory(), torch.from_numpy(f["image_u8"]).pin_memory()) for f in frames]
     pipe.feed(*host[0])
-    with pytest.raises(RuntimeError):
-        pipe.feed(*host[1]); pipe.feed(*host[2])               # a third un-consumed input has no buffer to go to
     for t in range(T):
-        if t >= 1 and t + 1 < T:
-            pipe.feed(*host[t + 1])
-        a_hat, raw = pipe.step()
+        a_hat, raw = pipe.step(next_inputs=host[t + 1] if t + 1 < T else None)
         assert torch.equal(a_hat, exp[t][0]), f"step {t}: a_hat differs"
         assert torch.equal(raw, exp[t][1]), f"step {t}: ensembled action differs"
-    with pytest.raises(RuntimeError):
-        pipe.step()                                            # nothing fed
+    with pytest.raises(RuntimeError, match="no inputs were fed"):
+        pipe.step()
+    # the engine is back to whole-step forwards after the phase captures
+    f = frames[0]
+    a = eng.forward_infer(torch.from_numpy(f["qpos"]).to(d), torch.from_numpy(f["image_u8"]).to(d))
+    assert torch.equal(a, exp[0][0])
     eng.check_flags()
