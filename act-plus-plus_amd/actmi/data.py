@@ -13,9 +13,11 @@ Differences, all on the host side of the step:
 * episode files are opened through ``open_episode``: HDF5 via ``h5py`` when it is importable (the reference's format:
   ``/observations/qpos``, ``/observations/qvel``, ``/observations/images/<cam>``, ``/action``, optional ``/base_action``,
   attrs ``sim`` / ``compress``), or ``.npz`` files with the same keys (``attrs_sim`` / ``attrs_compress`` entries) — what
-  the tests use, since neither h5py nor cv2 exists in the build container.  Compressed images (cv2.imdecode) and the
-  Diffusion-only augmentations (torchvision transforms) are therefore not handled: **parity unpinned** for those two
-  branches; everything else is checked against an independent restatement in ``tests/test_data_pipeline_cpu.py``."""
+  the tests use, since neither h5py nor cv2 exists in the build container;
+* compressed episodes (attr ``compress``: every frame a zero-padded JPEG byte string, utils.py:104-107) are decoded with PIL
+  (libjpeg, like cv2) and flipped to the B, G, R channel order ``cv2.imdecode(buf, 1)`` returns -- **parity unpinned** against
+  cv2 itself (absent here); the Diffusion-only augmentations (torchvision transforms, utils.py:141-156) are not handled.
+  Everything else is checked against an independent restatement in ``tests/test_data_pipeline_cpu.py``."""
 import fnmatch
 import os
 
@@ -55,6 +57,16 @@ def open_episode(path):
     except ImportError as e:                                     # pragma: no cover - h5py is absent in the build container
         raise RuntimeError(f"{path}: reading HDF5 episodes needs h5py") from e
     return h5py.File(path, "r")
+
+
+def imdecode_bgr(buf):
+    """``np.array(cv2.imdecode(buf, 1))`` (utils.py:104-107) without cv2: `buf` is a 1-D u8 array holding one JPEG (or PNG) file,
+    zero-padded to the episode's common length; the result is H x W x 3 u8 in cv2's B, G, R order."""
+    import io
+    from PIL import Image
+    with Image.open(io.BytesIO(np.ascontiguousarray(buf, dtype=np.uint8).tobytes())) as im:
+        rgb = np.asarray(im.convert("RGB"))
+    return np.ascontiguousarray(rgb[..., ::-1])
 
 
 def preprocess_base_action(base_action):
@@ -164,13 +176,14 @@ class EpisodicDataset(torch.utils.data.Dataset):
         with open_episode(dataset_path) as root:
             attrs = root.attrs
             is_sim = bool(attrs["sim"]) if "sim" in attrs else False         # legacy data lacks the attribute
-            if attrs.get("compress", False):
-                raise NotImplementedError(f"{dataset_path}: compressed images need cv2.imdecode (absent here)")
+            compressed = bool(attrs.get("compress", False))
             action = np.asarray(_read_action(root))
             original_action_shape = action.shape
             episode_len = original_action_shape[0]
             qpos = np.asarray(root["/observations/qpos"][start_ts])
             images = [np.asarray(root[f"/observations/images/{cam}"][start_ts]) for cam in self.camera_names]
+        if compressed:                                            # utils.py:104-107
+            images = [imdecode_bgr(buf) for buf in images]
         if is_sim:
             action = action[start_ts:]
             action_len = episode_len - start_ts

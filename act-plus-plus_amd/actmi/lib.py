@@ -129,6 +129,17 @@ def load():
         "actmi_op_unfold1d": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
         "actmi_op_ddim_step": ([vp, vp, C.c_int64, f32, f32, f32, f32, i32, vp], i32),
         "actmi_op_mish": ([vp, vp, C.c_int64, vp], i32),
+        "actmi_op_gelu": ([vp, vp, C.c_int64, vp], i32),
+        "actmi_op_gelu_bwd": ([vp, vp, vp, C.c_int64, vp], i32),
+        "actmi_op_dropout": ([vp, vp, C.c_int64, C.c_float, C.c_uint64, vp], i32),
+        "actmi_op_small_attention": ([vp, vp, i32, i32, i32, i32, i32, C.c_float, C.c_uint64, vp], i32),
+        "actmi_op_small_attention_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, C.c_float, C.c_uint64, vp], i32),
+        "actmi_op_soft_ce_dim1": ([vp, vp, i32, i32, i32, vp, vp, vp, vp], i32),
+        "actmi_op_argmax_l1": ([vp, vp, i32, i32, vp, vp, vp], i32),
+        "actmi_op_layernorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, C.c_float, vp, C.c_int64, vp], i32),
+        "actmi_op_colsum": ([vp, C.c_int64, vp, i32, i32, vp, C.c_int64, vp], i32),
+        "actmi_op_sum_batch": ([vp, C.c_int64, C.c_int64, vp, i32, i32, i32, i32, vp], i32),
+        "actmi_op_adamw": ([vp, vp, vp, vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, vp], i32),
         "actmi_op_u8_to_nhwc4": ([vp, vp, i32, i32, i32, i32, vp], i32),
         "actmi_op_last_error": ([], C.c_char_p),
         "actmi_debug_tensor": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i64)], i32),

@@ -421,6 +421,118 @@ def u8_to_nhwc4(image_u8):
     return out
 
 
+# ---- pieces of the latent-prior training step (csrc/prior.hip; reference train_latent_model.py:323-343) -----------------
+def gemm_t(A, Bm, ta=False, tb=False, bias=None, res=None, out=None, prec="f32"):
+    """C = A' @ B'^T (+ bias + res) with the transposed operand forms of the backward: ta: A is stored [K][M]; tb: B is stored
+    [K][N] (else [N][K], the nn.Linear layout).  Linear backward: dX = gemm_t(dY, W, tb=True); dW = gemm_t(dY, X, ta=True, tb=True)."""
+    lib = L.load()
+    if ta:
+        K, M = A.shape
+    else:
+        M, K = A.shape
+    N = Bm.shape[1] if tb else Bm.shape[0]
+    assert (Bm.shape[0] if tb else Bm.shape[1]) == K, (A.shape, Bm.shape, ta, tb)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    d = L.GemmDesc()
+    d.A, d.lda, d.mode, d.ta = A.data_ptr(), A.stride(0), 0, 1 if ta else 0
+    d.Bw, d.ldb, d.tb = Bm.data_ptr(), Bm.stride(0), 1 if tb else 0
+    d.bias = bias.data_ptr() if bias is not None else None
+    if res is not None:
+        d.res, d.ldres = res.data_ptr(), res.stride(0)
+    d.C, d.ldc = out.data_ptr(), out.stride(0)
+    d.M, d.N, d.K, d.groups = M, N, K, 1
+    d.prec = PREC[prec]
+    L.check(lib.actmi_op_gemm(C.byref(d), L.current_stream_ptr()), None, "op_gemm")
+    return out
+
+
+def gelu(x):
+    y = torch.empty_like(x)
+    L.check(L.load().actmi_op_gelu(_p(x), _p(y), x.numel(), L.current_stream_ptr()), None, "op_gelu")
+    return y
+
+
+def gelu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    L.check(L.load().actmi_op_gelu_bwd(_p(x), _p(dy), _p(dx), x.numel(), L.current_stream_ptr()), None, "op_gelu_bwd")
+    return dx
+
+
+def dropout(x, p, seed):
+    """y = x * keep(seed, i) / (1 - p); the backward is the same call on the gradient"""
+    y = torch.empty_like(x)
+    L.check(L.load().actmi_op_dropout(_p(x), _p(y), x.numel(), float(p), int(seed), L.current_stream_ptr()), None, "op_dropout")
+    return y
+
+
+def small_attention(qkv, nheads, causal=True, drop_p=0.0, seed=0):
+    """qkv [n,T,3D] (q | k | v) -> [n,T,D]; T <= 64, D / nheads <= 64"""
+    n, T, D3 = qkv.shape
+    D = D3 // 3
+    out = torch.empty((n, T, D), dtype=torch.float32, device=qkv.device)
+    L.check(L.load().actmi_op_small_attention(_p(qkv), _p(out), n, T, nheads, D // nheads, 1 if causal else 0, float(drop_p), int(seed),
+                                              L.current_stream_ptr()), None, "op_small_attention")
+    return out
+
+
+def small_attention_bwd(qkv, dout, nheads, causal=True, drop_p=0.0, seed=0):
+    n, T, D3 = qkv.shape
+    D = D3 // 3
+    dqkv = torch.empty_like(qkv)
+    L.check(L.load().actmi_op_small_attention_bwd(_p(qkv), _p(dout), _p(dqkv), n, T, nheads, D // nheads, 1 if causal else 0,
+                                                  float(drop_p), int(seed), L.current_stream_ptr()), None, "op_small_attention_bwd")
+    return dqkv
+
+
+def soft_ce_dim1(logits, target, want_grad=True):
+    """F.cross_entropy(logits [B,T,V], target [B,T,V] probabilities): classes along dim 1.  -> (loss [1], dlogits or None)"""
+    B, T, V = logits.shape
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    ws = torch.empty(B * V, dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    L.check(L.load().actmi_op_soft_ce_dim1(_p(logits), _p(target), B, T, V, _p(loss), _p(dl), _p(ws), L.current_stream_ptr()), None,
+            "op_soft_ce_dim1")
+    return loss, dl
+
+
+def argmax_l1(logits, target):
+    """mean |one_hot(argmax(logits, -1)) - target|"""
+    V = logits.shape[-1]
+    rows = logits.numel() // V
+    out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    ws = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    L.check(L.load().actmi_op_argmax_l1(_p(logits), _p(target), rows, V, _p(out), _p(ws), L.current_stream_ptr()), None, "op_argmax_l1")
+    return out
+
+
+def layernorm_bwd(x, w, dy, dw, db, ws, dx_add=None, eps=1e-5):
+    """-> dx; dw += , db += (views of the gradient arena)"""
+    M, D = x.shape
+    dx = torch.empty_like(x)
+    L.check(L.load().actmi_op_layernorm_bwd(_p(x), _p(w), _p(dy), _p(dx_add), _p(dx), _p(dw), _p(db), M, D, eps, _p(ws), ws.numel(),
+                                            L.current_stream_ptr()), None, "op_layernorm_bwd")
+    return dx
+
+
+def colsum(src, out, ws):
+    """out[n] += sum_m src[m][n]"""
+    M, N = src.shape
+    L.check(L.load().actmi_op_colsum(_p(src), src.stride(0), _p(out), M, N, _p(ws), ws.numel(), L.current_stream_ptr()), None, "op_colsum")
+
+
+def sum_batch(src, dst, accumulate=False):
+    """src [B,R,D] -> dst[R,D] (+)= sum_b src[b]"""
+    B, Rr, D = src.shape
+    L.check(L.load().actmi_op_sum_batch(_p(src), src.stride(0), src.stride(1), _p(dst), B, Rr, D, 1 if accumulate else 0,
+                                        L.current_stream_ptr()), None, "op_sum_batch")
+
+
+def adamw(p, g, m, v, lr, weight_decay, step, betas=(0.9, 0.999), eps=1e-8):
+    L.check(L.load().actmi_op_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(weight_decay), float(betas[0]),
+                                    float(betas[1]), float(eps), int(step), L.current_stream_ptr()), None, "op_adamw")
+
+
 class TemporalEnsemble:
     """Batched temporal ensembling state for E episodes (reference imitate_episodes.py:338-339, 402-411).
     Ring buffer [E,Q,Q,A] instead of the reference's [T,T+Q,A] per episode: only the last Q chunks can

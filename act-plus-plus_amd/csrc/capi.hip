@@ -445,4 +445,64 @@ int actmi_debug_tensor(actmi_handle h, const char* name, const float** dev_ptr, 
     return 0;
 }
 
+// ---- ops of the latent-prior training step (prior.hip; the LayerNorm backward, column sum and batch sum are the training
+// engine's own kernels) ------------------------------------------------------------------------------------------
+#define OPCHK(cond, msg) do { g_op_error.clear(); if (!(cond)) { g_op_error = msg; return ACTMI_E_INVALID; } } while (0)
+#define OPRC(call, what) do { const int rc_ = (call); if (rc_ != 0) { g_op_error = what; return rc_ == -2 ? ACTMI_E_SHAPE : ACTMI_E_LAUNCH; } return ACTMI_OK; } while (0)
+
+int actmi_op_gelu(const float* x, float* y, int64_t n, void* stream) {
+    OPCHK(x && y && n >= 0, "gelu: bad argument");
+    OPRC(launch_gelu(x, y, n, S(stream)), "gelu launch failed");
+}
+int actmi_op_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+    OPCHK(x && dy && dx && n >= 0, "gelu_bwd: bad argument");
+    OPRC(launch_gelu_bwd(x, dy, dx, n, S(stream)), "gelu_bwd launch failed");
+}
+int actmi_op_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+    OPCHK(x && y && n >= 0 && p >= 0.f && p < 1.f, "dropout: bad argument (0 <= p < 1)");
+    OPRC(launch_dropout(x, y, n, p, seed, S(stream)), "dropout launch failed");
+}
+int actmi_op_small_attention(const float* qkv, float* out, int n, int T, int H, int HD, int causal, float drop_p, uint64_t seed,
+                             void* stream) {
+    OPCHK(qkv && out, "small_attention: null pointer");
+    OPRC(launch_small_attention(qkv, out, n, T, H, HD, causal, drop_p, seed, S(stream)),
+         "small_attention: needs 1 <= T <= 64, 1 <= head_dim <= 64, 0 <= drop_p < 1");
+}
+int actmi_op_small_attention_bwd(const float* qkv, const float* dout, float* dqkv, int n, int T, int H, int HD, int causal,
+                                 float drop_p, uint64_t seed, void* stream) {
+    OPCHK(qkv && dout && dqkv, "small_attention_bwd: null pointer");
+    OPRC(launch_small_attention_bwd(qkv, dout, dqkv, n, T, H, HD, causal, drop_p, seed, S(stream)),
+         "small_attention_bwd: needs 1 <= T <= 64, 1 <= head_dim <= 64, 0 <= drop_p < 1");
+}
+int actmi_op_soft_ce_dim1(const float* logits, const float* target, int B, int T, int V, float* loss, float* dlogits, float* ws,
+                          void* stream) {
+    OPCHK(logits && target && loss && ws, "soft_ce_dim1: null pointer");
+    OPRC(launch_soft_ce_dim1(logits, target, B, T, V, loss, dlogits, ws, S(stream)), "soft_ce_dim1: bad shape");
+}
+int actmi_op_argmax_l1(const float* logits, const float* target, int rows, int V, float* out, float* ws, void* stream) {
+    OPCHK(logits && target && out && ws, "argmax_l1: null pointer");
+    OPRC(launch_argmax_l1(logits, target, rows, V, out, ws, S(stream)), "argmax_l1: bad shape");
+}
+int actmi_op_layernorm_bwd(const float* x, const float* w, const float* dy, const float* dx_add, float* dx, float* dw, float* db,
+                           int M, int D, float eps, float* ws, int64_t ws_floats, void* stream) {
+    OPCHK(x && w && dy && dx && dw && db && M >= 0, "layernorm_bwd: null pointer");
+    OPRC(launch_ln_bwd(x, w, dy, dx_add, dx, dw, db, M, D, eps, S(stream), ws, ws_floats), "layernorm_bwd: D must be a multiple of 4 and <= 2048");
+}
+int actmi_op_colsum(const float* src, int64_t ld, float* out, int M, int N, float* ws, int64_t ws_floats, void* stream) {
+    OPCHK(src && out && M >= 0 && N >= 0, "colsum: bad argument");
+    OPRC(launch_colsum(src, ld, out, M, N, S(stream), ws, ws_floats), "colsum launch failed");
+}
+int actmi_op_sum_batch(const float* src, int64_t batch_stride, int64_t ld, float* dst, int B, int R, int D, int accumulate,
+                       void* stream) {
+    OPCHK(src && dst && B >= 1, "sum_batch: bad argument");
+    OPRC(launch_sum_batch(src, batch_stride, ld, dst, B, R, D, accumulate, S(stream)), "sum_batch launch failed");
+}
+int actmi_op_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float weight_decay, float beta1, float beta2,
+                   float eps, int64_t step, void* stream) {
+    OPCHK(p && g && m && v && n >= 0 && step >= 1, "adamw: bad argument (step counts from 1)");
+    OPRC(launch_adamw_flat(p, g, m, v, n, lr, weight_decay, beta1, beta2, eps, step, S(stream)), "adamw launch failed");
+}
+#undef OPCHK
+#undef OPRC
+
 }  // extern "C"

@@ -208,6 +208,19 @@ int launch_split16_map(const float* src, float* dst, int64_t nfloats, const int*
                        uint32_t* flag, hipStream_t st);
 int launch_check_finite(const float* x, int64_t n, uint32_t* flag, uint32_t bit, hipStream_t st);
 int launch_dropout_bwd(const float* dy, float* dz, uint64_t seed, float p, int64_t n, hipStream_t st);
+// ---- latent-prior training pieces (prior.hip) ----------------------------------------------------------------
+int launch_gelu(const float* x, float* y, int64_t n, hipStream_t st);
+int launch_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, hipStream_t st);
+int launch_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, hipStream_t st);
+int launch_small_attention(const float* qkv, float* out, int n, int T, int H, int HD, int causal, float drop_p, uint64_t seed,
+                           hipStream_t st);
+int launch_small_attention_bwd(const float* qkv, const float* dout, float* dqkv, int n, int T, int H, int HD, int causal, float drop_p,
+                               uint64_t seed, hipStream_t st);
+int launch_soft_ce_dim1(const float* logits, const float* target, int B, int T, int V, float* loss, float* dlogits, float* ws,
+                        hipStream_t st);
+int launch_argmax_l1(const float* logits, const float* target, int rows, int V, float* out, float* ws, hipStream_t st);
+int launch_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float wd, float b1, float b2, float eps,
+                      int64_t step, hipStream_t st);
 int launch_attn_drop(const float* P, float* Pd, uint64_t seed, float p, int G, int Nq, int Nk, int ldp, hipStream_t st);
 int launch_attn_ds_drop(const float* P, float* dP, const float* delta, float scale, uint64_t seed, float p, int G, int Nq,
                         int Nk, int ldp, hipStream_t st);

@@ -365,6 +365,40 @@ int actmi_op_ddim_step(float* x, const float* eps, int64_t n, float inv_sqrt_at,
                        float sqrt_1m_aprev, int clip, void* stream);
 int actmi_op_mish(const float* x, float* y, int64_t n, void* stream);
 int actmi_op_u8_to_nhwc4(const uint8_t* image, float* out, int B, int Cam, int H, int W, void* stream);
+/* ---- training step of the VQ-ACT latent prior (reference detr/models/latent_model.py:8-56 as driven by
+ * train_latent_model.py:323-343: forward_pass, F.cross_entropy, torch.optim.AdamW).  The matrix products of its forward and backward
+ * are actmi_op_gemm calls (ta / tb select the transposed operands); these are the remaining pieces.  All fp32, no atomics. */
+/* nn.GELU() (exact erf form) and its derivative at the saved pre-activation */
+int actmi_op_gelu(const float* x, float* y, int64_t n, void* stream);
+int actmi_op_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* nn.Dropout: y[i] = keep(seed, i) ? x[i] / (1 - p) : 0.  The mask is a pure function of (seed, i): the backward is the same call
+ * on the gradient. */
+int actmi_op_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* nn.MultiheadAttention(batch_first) core for short sequences (T <= 64, head_dim <= 64): qkv [n][T][3*H*HD] as in_proj leaves it
+ * (q | k | v), out [n][T][H*HD] before out_proj; causal != 0 applies the triu(diagonal=1) mask of latent_model.py:26; drop_p is the
+ * attention-weight dropout.  The backward recomputes the weights and writes dqkv [n][T][3*H*HD] = (dq | dk | dv). */
+int actmi_op_small_attention(const float* qkv, float* out, int n, int T, int H, int HD, int causal, float drop_p, uint64_t seed,
+                             void* stream);
+int actmi_op_small_attention_bwd(const float* qkv, const float* dout, float* dqkv, int n, int T, int H, int HD, int causal,
+                                 float drop_p, uint64_t seed, void* stream);
+/* F.cross_entropy(logits [B][T][V], target [B][T][V]) with probability targets, mean reduction -- the class axis is dim 1 (T), as
+ * train_latent_model.py:329 calls it.  loss: one float; dlogits (optional): gradient of the loss; ws: B*V floats of scratch. */
+int actmi_op_soft_ce_dim1(const float* logits, const float* target, int B, int T, int V, float* loss, float* dlogits, float* ws,
+                          void* stream);
+/* mean |one_hot(argmax(logits, -1)) - target| over [rows][V] (train_latent_model.py:331-334); ws: `rows` floats of scratch */
+int actmi_op_argmax_l1(const float* logits, const float* target, int rows, int V, float* out, float* ws, void* stream);
+/* nn.LayerNorm backward at the saved input x: dx = dx_add (optional) + d/dx, dw += , db += (zero them first); with ws
+ * (>= 2*D*min(1024, ceil(M/4)) floats) the parameter gradients are summed in a fixed order */
+int actmi_op_layernorm_bwd(const float* x, const float* w, const float* dy, const float* dx_add, float* dx, float* dw, float* db,
+                           int M, int D, float eps, float* ws, int64_t ws_floats, void* stream);
+/* out[n] += sum_m src[m][n] (bias gradients); with ws (>= ceil(M/256)*N floats) in a fixed order */
+int actmi_op_colsum(const float* src, int64_t ld, float* out, int M, int N, float* ws, int64_t ws_floats, void* stream);
+/* dst[r][d] (+)= sum_b src[b*batch_stride + r*ld + d] (gradient of a table added to every sample: nn.Embedding positions) */
+int actmi_op_sum_batch(const float* src, int64_t batch_stride, int64_t ld, float* dst, int B, int R, int D, int accumulate,
+                       void* stream);
+/* torch.optim.AdamW update of one flat fp32 tensor (decoupled decay, bias correction with `step` counted from 1) */
+int actmi_op_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float weight_decay, float beta1, float beta2,
+                   float eps, int64_t step, void* stream);
 const char* actmi_op_last_error(void);
 
 /* intermediate activations of the last forward (parity tests): name in {"conv1","maxpool","layer1".."layer4",

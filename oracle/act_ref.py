@@ -314,6 +314,38 @@ def latent_model_forward(sd, x, num_head=8, num_layer=3):
     return F.linear(h, sd["output_layer.weight"], sd["output_layer.bias"])
 
 
+def latent_model_train_step(sd, x, labels, lr=None, steps=0, num_head=8, num_layer=3, weight_decay=0.01):
+    """One forward_pass of train_latent_model.py:323-343 with the dropout modules off (the parity mode: torch's dropout stream
+    cannot be reproduced): logits, ``F.cross_entropy(output_logits, gt_labels)`` -- [B, T, V] probabilities as targets, so the
+    class axis is dim 1 --, the one-hot L1 metric of :331-334, the gradients of every parameter, and (lr given) the parameters
+    after ``steps`` iterations of ``torch.optim.AdamW(parameters, lr=lr)`` on the same batch (:395-404).  float64 throughout."""
+    prm = {k: v.detach().double().clone().requires_grad_(True) for k, v in sd.items()}
+    x, labels = x.double(), labels.double()
+
+    def fwd():
+        logits = latent_model_forward(prm, x, num_head, num_layer)
+        return logits, F.cross_entropy(logits, labels)
+
+    logits, loss = fwd()
+    grads = dict(zip(prm.keys(), torch.autograd.grad(loss, list(prm.values()))))
+    with torch.no_grad():
+        onehot = F.one_hot(torch.argmax(logits, dim=-1), num_classes=labels.shape[-1]).double()
+        l1 = F.l1_loss(onehot, labels, reduction="mean")
+    out = {"logits": logits.detach(), "loss": loss.detach(), "l1_error": l1, "grads": grads}
+    if lr is not None and steps > 0:
+        opt = torch.optim.AdamW(list(prm.values()), lr=lr, weight_decay=weight_decay)
+        losses = []
+        for _ in range(steps):
+            opt.zero_grad()
+            _, l = fwd()
+            l.backward()
+            opt.step()
+            losses.append(float(l))
+        out["params_after"] = {k: v.detach().clone() for k, v in prm.items()}
+        out["losses"] = losses
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # imitate_episodes.py
 # ------------------------------------------------------------------------------------------------

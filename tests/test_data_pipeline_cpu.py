@@ -117,3 +117,39 @@ def test_load_data_and_prefetcher_end_to_end(tmp_path):
     assert n == 5
     vb = next(iter(va))
     assert tuple(vb[0].shape) == (2, 2, 12, 16, 3)
+
+
+def test_compressed_episode_frames_are_decoded_like_cv2_imdecode(tmp_path):
+    """utils.py:104-107: attr `compress` -> every stored frame is a zero-padded JPEG byte string; the loader returns what
+    ``cv2.imdecode(buf, 1)`` would: the decoded picture in B, G, R order.  cv2 is absent: the expected pixels come from PIL's
+    decoder on the unpadded bytes (parity with cv2 itself unpinned)."""
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    T, cams = 6, ["top"]
+    ep = _write_episode(str(tmp_path / "raw.npz"), T, cams, rng, True)
+    os.remove(str(tmp_path / "raw.npz"))
+    frames = np.kron(rng.integers(0, 256, (T, 6, 8, 3), dtype=np.uint8), np.ones((1, 4, 4, 1), dtype=np.uint8))   # smooth blocks
+    bufs, expect = [], []
+    for t in range(T):
+        bio = io.BytesIO()
+        Image.fromarray(frames[t]).save(bio, format="JPEG", quality=90)
+        raw = np.frombuffer(bio.getvalue(), dtype=np.uint8)
+        bufs.append(raw)
+        expect.append(np.asarray(Image.open(io.BytesIO(raw.tobytes())).convert("RGB"))[..., ::-1])
+    L = max(len(b) for b in bufs) + 7
+    padded = np.zeros((T, L), dtype=np.uint8)
+    for t, b in enumerate(bufs):
+        padded[t, :len(b)] = b
+    ep["/observations/images/top"] = padded
+    ep["attrs_compress"] = np.array(True)
+    path = str(tmp_path / "episode_0.npz")
+    np.savez(path, **ep)
+    stats, lens = D.get_norm_stats([path])
+    ds = D.EpisodicDataset([path], cams, stats, [0], lens, 10, "ACT")
+    for idx in (0, 3, T - 1):
+        img, _, _, _ = ds[idx]
+        assert img.dtype == torch.uint8 and tuple(img.shape) == (1, 24, 32, 3)
+        assert np.array_equal(img[0].numpy(), expect[idx])
+        got = img[0].numpy().astype(int)                                   # it IS the picture, channel-flipped (JPEG is lossy)
+        assert np.abs(got[..., ::-1] - frames[idx]).mean() < 0.5 * np.abs(got - frames[idx]).mean()

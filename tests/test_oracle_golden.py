@@ -194,3 +194,57 @@ def test_oracle_latent_prior_matches_reference():
     with torch.no_grad():
         lo = R.latent_model_forward({k: torch.from_numpy(v) for k, v in sd.items()}, torch.from_numpy(z["x"]))
     assert np.abs(lo.numpy() - z["logits"]).max() < 2e-5
+
+
+def _latent_prior_train_fixture():
+    import os
+    from actmi.latent_model import latent_model_spec
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "latent_prior_train.npz"))
+    vq = int(z["vq"])
+    sd = W.generate_latent_model_state_dict(latent_model_spec(vq, vq, vq), int(z["seed_w"]))
+    return z, sd, vq
+
+
+def check_against_prior_train_fixture(z, grads, params1, params3, rel=2e-5):
+    """gradients / parameters (dicts of arrays) against the stored ones: full tensors where the fixture holds them, else the
+    first 256 elements and the norm"""
+    for k in [f[2:] for f in z.files if f.startswith("g:")]:
+        ref = z["g:" + k]
+        got = np.asarray(grads[k], dtype=np.float64)
+        part = got if ref.shape == got.shape else got.reshape(-1)[:256]
+        if float(np.abs(ref).max()) < 1e-6:
+            # a vector added at every position moves the logits by a constant along T -- the class axis of the reference's cross
+            # entropy -- so output_layer.bias and the last LayerNorm's bias have EXACTLY zero gradient: rounding noise on both sides
+            assert float(np.abs(got).max()) < 1e-6, k
+            continue
+        scale = float(np.abs(ref).max())
+        assert np.abs(part - ref).max() <= rel * scale + 1e-9, (k, float(np.abs(part - ref).max()), scale)
+        assert abs(np.sqrt((got ** 2).sum()) - float(z["gnorm:" + k])) <= rel * float(z["gnorm:" + k]) + 1e-9, k
+        for tag, prm in (("p1:", params1), ("p3:", params3)):
+            if prm is None:
+                continue
+            ref = z[tag + k]
+            got = np.asarray(prm[k], dtype=np.float64)
+            part = got if ref.shape == got.shape else got.reshape(-1)[:256]
+            # AdamW's first steps move every weight by ~lr * g / (|g| + eps) whatever the gradient's size: absolute bound in units
+            # of lr, over the elements whose gradient is clear of eps = 1e-8 (below it the update amplifies rounding noise of g)
+            clear = np.abs(z["g:" + k]) > 1e-5 * max(float(np.abs(z["g:" + k]).max()), 1e-30)
+            assert clear.mean() > 0.5, k
+            assert np.abs(part - ref)[clear].max() <= 0.02 * float(z["lr"]), (tag, k, float(np.abs(part - ref)[clear].max()))
+
+
+def test_oracle_latent_prior_training_step_matches_reference():
+    """train_latent_model.py:323-343, 395-404 on the reference's own module: loss (class axis = dim 1), L1 metric, every
+    gradient, and the parameters after 1 and 3 AdamW steps"""
+    z, sd, vq = _latent_prior_train_fixture()
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    x, y = torch.from_numpy(z["inputs"]), torch.from_numpy(z["labels"])
+    r1 = R.latent_model_train_step(tsd, x, y, lr=float(z["lr"]), steps=1)
+    r3 = R.latent_model_train_step(tsd, x, y, lr=float(z["lr"]), steps=int(z["steps"]))
+    assert np.abs(r1["logits"].numpy() - z["logits"]).max() < 2e-5
+    assert abs(float(r1["loss"]) - float(z["losses"][0])) < 1e-5 and abs(float(r1["l1_error"]) - float(z["l1_error"])) < 1e-6
+    assert np.abs(np.array(r3["losses"]) - z["losses"]).max() < 1e-5
+    check_against_prior_train_fixture(z, {k: v.numpy() for k, v in r1["grads"].items()},
+                                      {k: v.numpy() for k, v in r1["params_after"].items()},
+                                      {k: v.numpy() for k, v in r3["params_after"].items()})
+

@@ -331,6 +331,62 @@ def cross_check_oracle(cfg, out, sd_np, inp, tol=2e-5):
             assert dd < 5e-5 * max(1.0, abs(float(r[k])))
 
 
+def make_latent_prior_train_fixture(ref):
+    """The prior's TRAINING step from the reference's own module and torch's autograd / AdamW (train_latent_model.py:323-343,
+    395-404), dropout off (module in eval mode; gradients enabled, so nn.MultiheadAttention takes its regular path).  Default
+    width / depth (256, 8 heads, 3 blocks); vq_class = vq_dim = 8 because the reference's cross entropy needs T == V.  The
+    weights are the seeded synthetic ones (not stored); gradients and updated parameters are stored in full for the small
+    tensors and as norm + first 256 elements for the matrices."""
+    from actmi import weights as W
+    from actmi.latent_model import latent_model_spec
+    vq, n, lr, steps = 8, 5, 1e-3, 3
+    m = ref.lm.Latent_Model_Transformer(vq, vq, vq)
+    spec = latent_model_spec(vq, vq, vq)
+    sd_np = W.generate_latent_model_state_dict(spec, 41)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    m.eval()
+    pick = (W.uniform01(42, "lm:labels", n * vq) * vq).astype(np.int64).reshape(n, vq).clip(0, vq - 1)
+    labels = np.zeros((n, vq, vq), dtype=np.float32)
+    for b in range(n):
+        for t in range(vq):
+            labels[b, t, pick[b, t]] = 1.0
+    gt = torch.from_numpy(labels)
+    inputs = torch.cat([torch.zeros_like(gt)[:, [0]], gt[:, :-1]], dim=1)            # train_latent_model.py:327
+    opt = torch.optim.AdamW(m.parameters(), lr=lr)                                   # :361
+    out = {"vq": np.array(vq), "seed_w": np.array(41), "lr": np.array(lr), "steps": np.array(steps), "labels": labels,
+           "inputs": inputs.numpy()}
+    losses = []
+    for it in range(steps):
+        opt.zero_grad()
+        logits = m(inputs)
+        loss = torch.nn.functional.cross_entropy(logits, gt)                         # :329
+        loss.backward()
+        if it == 0:
+            with torch.no_grad():
+                onehot = torch.nn.functional.one_hot(torch.argmax(logits, dim=-1), num_classes=vq).float()
+                out["l1_error"] = torch.nn.functional.l1_loss(onehot, gt, reduction="mean").numpy()
+            out["logits"] = logits.detach().numpy()
+            for k, prm in m.named_parameters():
+                g = prm.grad.detach().numpy()
+                out["gnorm:" + k] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
+                out["g:" + k] = g.copy() if g.size <= 4096 else g.reshape(-1)[:256].copy()
+        opt.step()
+        losses.append(float(loss.detach()))
+        if it in (0, steps - 1):
+            for k, prm in m.named_parameters():
+                v = prm.detach().numpy()
+                out[f"p{it + 1}:" + k] = v.copy() if v.size <= 4096 else v.reshape(-1)[:256].copy()
+    out["losses"] = np.array(losses)
+    path = os.path.join(GOLD, "latent_prior_train.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path)/1024:.1f} KB); losses {losses}")
+    sys.path.insert(0, ROOT)
+    from oracle import act_ref as R
+    r = R.latent_model_train_step({k: torch.from_numpy(v) for k, v in sd_np.items()}, inputs, gt, lr=lr, steps=steps)
+    print(f"  oracle loss {float(r['loss']):.7f} ref {losses[0]:.7f}; losses after steps {r['losses']}")
+    assert abs(float(r["loss"]) - losses[0]) < 1e-5 and abs(r["losses"][-1] - losses[-1]) < 1e-5
+
+
 def make_latent_prior_fixture(ref):
     """VQ-ACT prior: the reference's Latent_Model_Transformer (latent_model.py:35-56) in eval mode on one-hot prefixes."""
     from actmi import weights as W
@@ -389,6 +445,9 @@ def main():
     if not args.only or args.only == "latent_prior":
         print("== latent_prior")
         make_latent_prior_fixture(ref)
+    if not args.only or args.only == "latent_prior_train":
+        print("== latent_prior_train")
+        make_latent_prior_train_fixture(ref)
     for name, j in jobs.items():
         if args.only and name != args.only:
             continue
