@@ -578,7 +578,9 @@ class InferPipeline:
         """HIP maps its streams onto a few hardware queues (4 by default), in order of creation.  The barrier packet behind an
         SDMA copy (the event record that publishes it) holds up whatever shares the copy stream's queue: measured, one of the
         transformer's two branches sat out the whole 0.56 ms copy (profiles/r03_h2d_timeline.txt), and a high-priority copy
-        stream slowed every kernel of the step instead.  Which queue a stream lands on is not visible through the API, so the
+        stream slowed every kernel of the step instead, and so did a stream with a hardware queue of its own
+        (hipExtStreamCreateWithCUMask: 6.3 ms per step against 4.4) and GPU_MAX_HW_QUEUES=8 -- more than four active queues are
+        time-sliced on this part.  Which queue a stream lands on is not visible through the API, so the
         pipeline times a few steps over each of `n_cand` consecutive streams and keeps the one that does not collide."""
         dev = self.dev
         if n_cand == 1:

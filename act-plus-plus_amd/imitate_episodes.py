@@ -324,7 +324,9 @@ def eval_bc(config, ckpt_name, save_episode=True, num_rollouts=50, policy=None, 
         if verbose:
             print(summary_str)
             if n_queries:
-                print(f"policy queries: {n_queries} in {t_policy:.2f} s on rank 0 = {n_queries / max(t_policy, 1e-9):.1f} steps/s")
+                # issue-to-host latency summed over the queries: with two groups in flight these intervals overlap each other and the
+                # simulators, so this is a latency figure, not wall time ("avg fps" above is the throughput)
+                print(f"policy queries: {n_queries} on rank 0, mean issue-to-host latency {1e3 * t_policy / n_queries:.2f} ms per query group")
         os.makedirs(ckpt_dir, exist_ok=True)
         result_file_name = "result_" + ckpt_name.split(".")[0] + ".txt"
         with open(os.path.join(ckpt_dir, result_file_name), "w") as f:

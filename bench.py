@@ -538,9 +538,10 @@ def train_rig(cfg, B, dev, seed, world, train_prec=None):
     inp = W.generate_inputs(cfg, B, seed=seed, with_actions=True)
     t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
 
-    def step(i):
+    def step(i, batch=None):
         eng.zero_grad()
-        out = eng.forward_train(t["qpos"], t["image_u8"], t["actions"], t["is_pad"], eps=t["eps"])
+        image, qpos, actions, is_pad = batch if batch is not None else (t["image_u8"], t["qpos"], t["actions"], t["is_pad"])
+        out = eng.forward_train(qpos, image, actions, is_pad, eps=t["eps"])
         if world > 1 and os.environ.get("ACTMI_DP_MODE", "zero1") != "allreduce":
             # data parallel, SURVEY 8 f1: bucketed reduce-scatter over RCCL (transformer buckets under the backbone backward),
             # fused AdamW on the owned 1/world of the arena, all-gather of the updated parameters
@@ -550,6 +551,7 @@ def train_rig(cfg, B, dev, seed, world, train_prec=None):
             eng.backward_allreduce(1.0 / world)   # bucketed all-reduce, transformer range under the backbone backward; full AdamW
             eng.adamw_step(1e-5, 1e-5, 1e-4, step=i + 1)
         return out
+    step.host_batch = lambda: tuple(torch.from_numpy(inp[k]).pin_memory() for k in ("image_u8", "qpos", "actions", "is_pad"))
     return eng, step
 
 
@@ -574,8 +576,25 @@ def train_record(cfg, B, dev, steps, warmup, train_prec=None):
     prof, rows, gpu_ms = kernel_table(L.profile_report(), steps)
     dom, ach = dominant(prof)
     assert torch.isfinite(out["loss"]).all()
+    # the same steps fed from the HOST the way train_bc feeds them: u8 NHWC batches in pinned memory, copied by
+    # actmi.data.DevicePrefetcher on a side stream while the previous step computes (the reference moves f32 images, 4x the bytes,
+    # synchronously in front of every step: imitate_episodes.py:529-532)
+    from actmi.data import DevicePrefetcher
+    host = step.host_batch()
+    feed = DevicePrefetcher((host for _ in range(steps + 1)), device=dev)
+    step(warmup + steps, next(feed))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step(warmup + steps + 1 + i, next(feed))
+    torch.cuda.synchronize(dev)
+    dt_fed = time.perf_counter() - t0
+    assert torch.isfinite(out["loss"]).all()
     del eng
     return {"per_gpu_batch": B, "steps": steps, "ms_per_step": dt / steps * 1e3, "samples_per_s": B * steps / dt,
+            "host_fed": {"ms_per_step": dt_fed / steps * 1e3, "h2d_bytes_per_step": int(sum(t_.numel() * t_.element_size() for t_ in host)),
+                         "note": "every step's batch (u8 NHWC frames, qpos, actions, is_pad) copied from pinned host memory by "
+                                 "actmi.data.DevicePrefetcher on a side stream under the previous step"},
             "train_steps_per_s": steps / dt,
             "arithmetic": ("fp32 storage / accumulation / master weights / AdamW state, ONE bf16 MFMA product per fp32 product in every "
                            "GEMM and implicit-GEMM convolution of the step (opt-in train_prec=bf16: BASELINE config 3 as written; "
