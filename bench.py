@@ -230,9 +230,7 @@ class InferRig:
             try:
                 # forward + ensemble as ONE graph launch.  The with_h2d leg uses engine.InferPipeline instead: two input buffers,
                 # the step as a trunk graph and a transformer graph, the H2D copy of the NEXT step's frames beside the latter.
-                from actmi.engine import InferPipeline
                 self.replay = self.eng.capture_infer(B, with_ensemble=self.ens)
-                self.pipe = InferPipeline(self.eng, B, with_ensemble=self.ens)
             except Exception as e:                               # capture unsupported -> eager launches
                 log(f"hipGraph capture failed ({e}); falling back to eager launches")
                 self.replay, self.pipe = None, None
@@ -273,6 +271,12 @@ class InferRig:
         for _ in range(warmup):
             self.step()
         sync()
+        if with_h2d and self.replay is not None and self.pipe is None:
+            try:                                             # built on first use: the headline leg never sees its graphs or streams
+                from actmi.engine import InferPipeline
+                self.pipe = InferPipeline(self.eng, self.B, with_ensemble=self.ens)
+            except Exception as e:                           # noqa: BLE001
+                log(f"InferPipeline unavailable ({e}); the with_h2d leg copies in front of every step")
         if with_h2d and self.pipe is not None:
             pipe, nxt = self.pipe, (self.qpos_host, self.image_host)
             t0 = time.perf_counter()
