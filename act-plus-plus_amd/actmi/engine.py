@@ -595,10 +595,10 @@ class InferPipeline:
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
                 self.feed(hq, him)
-                for i in range(6):
-                    self.step(next_inputs=(hq, him) if i < 5 else None)
+                for i in range(12):
+                    self.step(next_inputs=(hq, him) if i < 11 else None)
                 torch.cuda.synchronize(dev)
-                dt.append((time.perf_counter() - t0) / 6)
+                dt.append((time.perf_counter() - t0) / 12)
             trials.append((dt[1], cs))
         self.fed, self.ran, self.k_run = [False, False], [False, False], 0
         if ens is not None:

@@ -445,6 +445,20 @@ def bench_infer(args, cfg, B, ctx):
             break
         except Exception:
             continue
+    # the two flavours of the same gemm.hip main loop (implicit-GEMM convolutions / row-major transformer products) carry 26 % of the
+    # step each: which one is "dominant" flips between boxes, so the other one is reported beside it whenever it is within 10 %
+    runner_up = None
+    if len(prof) > 1 and prof[1]["ms"] >= 0.9 * dom["ms"] and prof[1]["flops"] > 0:
+        r2 = prof[1]
+        a2 = r2["flops"] / (r2["ms"] * 1e-3) / 1e12
+        t2 = None
+        try:
+            t2 = tj["kernels"][r2["name"].split("[")[0]]["traffic_bytes_per_launch"] if (traffic is not None and B == 8) else None
+        except Exception:                                    # noqa: BLE001
+            pass
+        runner_up = {"kernel": r2["name"], "achieved": a2, "frac": a2 / kernel_peak(r2["name"])[0], "share_of_dominant_time": r2["ms"] / dom["ms"],
+                     "avg_launch_us": r2["ms"] * 1e3 / r2["count"], "launches_per_step": r2["count"] / args.steps,
+                     "algorithmic_bytes_per_launch": r2["bytes"] / r2["count"], "traffic": t2}
     prec = os.environ.get("ACTMI_GEMM_PREC", "f16x3")
     out = {
         "metric": "policy steps/sec (4x480x640 cams, chunk=100, bs=8)",
@@ -469,7 +483,7 @@ def bench_infer(args, cfg, B, ctx):
                      "frac_of_native_fp32_mfma_peak": ach / PEAK_FP32_MATRIX_TFLOPS,
                      "avg_launch_us": dom["ms"] * 1e3 / dom["count"], "launches_per_step": dom["count"] / args.steps,
                      "flop_per_launch": dom["flops"] / dom["count"],
-                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["count"]},
+                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["count"], "runner_up": runner_up},
         "whole_step": {"gflop_per_sample_live": GFLOP_PER_SAMPLE_LIVE,
                        "achieved_tflops_live": value / world * GFLOP_PER_SAMPLE_LIVE / 1e3,
                        "frac_of_fp32_matrix_peak": value / world * GFLOP_PER_SAMPLE_LIVE / 1e3 / PEAK_FP32_MATRIX_TFLOPS,
