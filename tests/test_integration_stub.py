@@ -59,9 +59,7 @@ def test_stale_binding_is_rejected_by_struct_size():
     """actmi_create checks struct_size before anything else (no HIP call yet): a binding built against an older header fails
     with ACTMI_E_INVALID and a message naming both sizes."""
     ns = _stub_namespace()
-    lib, Cfg = ns["lib"], ns["Cfg"]
-    lib.actmi_last_error.restype = C.c_char_p
-    lib.actmi_last_error.argtypes = [C.c_void_p]
+    lib, Cfg = ns["lib"], ns["Cfg"]              # (the stub itself declares actmi_last_error's return type)
 
     class OldCfg(C.Structure):                       # round-2 INTEGRATION.md: no struct_size, ends at kl_weight
         _fields_ = [(n, C.c_int32) for n in ("num_cams", "image_h", "image_w", "base_width", "hidden_dim", "nheads",
@@ -76,6 +74,17 @@ def test_stale_binding_is_rejected_by_struct_size():
     cfg = Cfg(C.sizeof(Cfg) - 12, 4, 480, 640, 64, 512, 8, 3200, 4, 7, 100, 14, 16, 32, 1, 8, 0, 10.0, 0, 0, 0)
     assert lib.actmi_create(C.byref(cfg), C.byref(h)) == -1
     assert str(C.sizeof(Cfg)).encode() in lib.actmi_last_error(None)
+
+
+def test_stub_error_path_raises_with_the_library_message():
+    """a config the library refuses (here: 7 heads on a width of 512; on a box without a GPU the missing device is reported
+    first) must surface as the RuntimeError the stub promises, text included -- not as a ctypes conversion error"""
+    ns = _stub_namespace()
+    a = dict(camera_names=["a"], hidden_dim=512, nheads=7, dim_feedforward=3200, enc_layers=4, dec_layers=7, num_queries=100,
+             action_dim=16, no_encoder=False, kl_weight=10)
+    with pytest.raises(RuntimeError) as e:
+        ns["ACTPolicy"](a)
+    assert len(str(e.value)) > 8, str(e.value)
 
 
 @pytest.mark.gpu
