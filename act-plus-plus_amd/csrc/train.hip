@@ -151,6 +151,26 @@ unsigned* amax_pre(actmi_ctx* ctx, const float* out, hipStream_t st) {
 // ctx->bwd_wscale (2^8 unless a parameter is too large for it: engine_calibrate_weight_scales)
 
 int pick_splitk(int M, int N, int groups, int K) {
+    // outputs of at least one 128x128 tile per side: the launch runs 128x128 tiles, two per CU = 512 at a time.  Choose the split
+    // that fills whole rounds of 512 (layer4's weight gradient: 576 workgroups unsplit = one full round + a round of 64 that lasts
+    // as long -- 132 TF; layer3's: 432): the smallest S within 3 % of the best fill, at least 16 K tiles per split.
+    static const bool fill_rule = !(getenv("ACTMI_WGRAD_SPLIT_FILL") && getenv("ACTMI_WGRAD_SPLIT_FILL")[0] == '0');
+    if (fill_rule && M >= 128 && N >= 128) {
+        const long w = (long)((M + 127) / 128) * ((N + 127) / 128) * groups;
+        const long nk = (K + 31) / 32;
+        long smax = nk / 16;
+        if (smax > 64) smax = 64;
+        if (smax < 1) smax = 1;
+        double best = 0.0;
+        for (long S = 1; S <= smax; ++S) {
+            const double e = (double)(w * S) / (512.0 * (double)((w * S + 511) / 512));
+            if (e > best) best = e;
+        }
+        for (long S = 1; S <= smax; ++S) {
+            const double e = (double)(w * S) / (512.0 * (double)((w * S + 511) / 512));
+            if (e >= best - 0.03) return (int)S;
+        }
+    }
     const long tiles = (long)((M + 127) / 128) * ((N + 63) / 64) * groups;
     long s = 1024 / (tiles > 0 ? tiles : 1);
     const long nk = (K + 31) / 32;
