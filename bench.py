@@ -717,7 +717,8 @@ def bench_train(args, cfg, B, ctx):
         "whole_step": {"gflop_per_sample_live": GFLOP_TRAIN_PER_SAMPLE_LIVE,
                        "achieved_tflops_live": value / world * GFLOP_TRAIN_PER_SAMPLE_LIVE / 1e3,
                        "gpu_kernel_ms_per_step": gpu_ms / args.steps},
-        "kernels": [{k: r[k] for k in ("name", "launches_per_step", "avg_us", "share", "tflops")} for r in rows[:16]],
+        "kernels": [{k: r[k] for k in ("name", "launches_per_step", "avg_us", "share", "tflops")}
+                    for r in (rows if os.environ.get("ACTMI_PROF_SHAPES") == "1" else rows[:16])],
     }
 
 
