@@ -55,6 +55,14 @@ class GemmDesc(C.Structure):
     ]
 
 
+class AttnBwdDesc(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p), ("d_o", C.c_void_p), ("lse", C.c_void_p),
+                ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p)] + \
+               [(n, C.c_int64) for n in ("q_bs", "q_rs", "k_bs", "k_rs", "v_bs", "v_rs", "dq_bs", "dq_rs", "dk_bs", "dk_rs", "dv_bs", "dv_rs")] + \
+               [("kpm", C.c_void_p), ("kpm_bs", C.c_int64)] + [(n, C.c_int32) for n in ("B", "H", "Nq", "Nk", "HD")] + \
+               [("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("delta_ws", C.c_void_p), ("do_scale", C.c_void_p), ("amax_out", C.c_void_p)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [
         ("Q", C.c_void_p), ("q_bs", C.c_int64), ("q_rs", C.c_int64),
@@ -115,6 +123,7 @@ def load():
         "actmi_op_pow2_scale": ([vp, C.c_int64, i32, i32, vp, vp], i32),
         "actmi_op_splitk_combine": ([vp, i32, C.c_int64, C.c_int64, i32, i32, vp, vp, vp, C.c_int64, i32, vp, C.c_int64, vp], i32),
         "actmi_op_attention": ([C.POINTER(AttnDesc), vp], i32),
+        "actmi_op_attention_bwd": ([C.POINTER(AttnBwdDesc), vp], i32),
         "actmi_op_layernorm": ([vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp], i32),
         "actmi_op_maxpool3x3s2": ([vp, vp, i32, i32, i32, i32, vp], i32),
         "actmi_op_conv1": ([vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),

@@ -299,6 +299,36 @@ def attention(q, k, v, nheads, kpm=None, q_shared=False, want_lse=False, split=T
     return (out, lse) if want_lse else out
 
 
+def attention_bwd(q, k, v, out, lse, dout, nheads, kpm=None, drop_p=0.0, drop_seed=0, do_scale=None, want_amax=False):
+    """dq, dk, dv of ``attention`` (f16x3, no materialised scores): q [B,Nq,D], k / v [B,Nk,D] (row-strided views allowed),
+    out / dout [B,Nq,D] contiguous, lse [B,H,Nq] from ``attention(..., want_lse=True)``."""
+    lib = L.load()
+    B, Nk, D = k.shape
+    Nq = q.shape[1]
+    dq = torch.empty((B, Nq, D), dtype=torch.float32, device=k.device)
+    dk = torch.empty((B, Nk, D), dtype=torch.float32, device=k.device)
+    dv = torch.empty((B, Nk, D), dtype=torch.float32, device=k.device)
+    ws = torch.empty(B * nheads * Nq, dtype=torch.float32, device=k.device)
+    amax = torch.zeros(1, dtype=torch.int32, device=k.device) if want_amax else None
+    d = L.AttnBwdDesc()
+    d.q, d.q_bs, d.q_rs = q.data_ptr(), q.stride(0), q.stride(1)
+    d.k, d.k_bs, d.k_rs = k.data_ptr(), k.stride(0), k.stride(1)
+    d.v, d.v_bs, d.v_rs = v.data_ptr(), v.stride(0), v.stride(1)
+    d.o, d.d_o, d.lse = out.data_ptr(), dout.data_ptr(), lse.data_ptr()
+    d.dq, d.dq_bs, d.dq_rs = dq.data_ptr(), dq.stride(0), dq.stride(1)
+    d.dk, d.dk_bs, d.dk_rs = dk.data_ptr(), dk.stride(0), dk.stride(1)
+    d.dv, d.dv_bs, d.dv_rs = dv.data_ptr(), dv.stride(0), dv.stride(1)
+    if kpm is not None:
+        d.kpm, d.kpm_bs = kpm.data_ptr(), kpm.stride(0)
+    d.B, d.H, d.Nq, d.Nk, d.HD = B, nheads, Nq, Nk, D // nheads
+    d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)
+    d.delta_ws = ws.data_ptr()
+    d.do_scale = do_scale.data_ptr() if do_scale is not None else None
+    d.amax_out = amax.data_ptr() if amax is not None else None
+    L.check(lib.actmi_op_attention_bwd(C.byref(d), L.current_stream_ptr()), None, "op_attention_bwd")
+    return (dq, dk, dv, amax) if want_amax else (dq, dk, dv)
+
+
 def layernorm(x, w, b, res=None, res_mod=0, w2=None, b2=None, eps=1e-5):
     lib = L.load()
     M, D = x.shape

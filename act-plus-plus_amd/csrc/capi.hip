@@ -276,6 +276,24 @@ int actmi_op_attention(const actmi_attn_desc* d, void* stream) {
     return launch_attention(*d, S(stream), &g_op_error);
 }
 
+int actmi_op_attention_bwd(const actmi_attn_bwd_desc* d, void* stream) {
+    g_op_error.clear();
+    if (!d || !d->o || !d->delta_ws) { g_op_error = "attention_bwd: null descriptor / output / scratch"; return ACTMI_E_INVALID; }
+    const int64_t D = (int64_t)d->H * d->HD;
+    if (launch_attn_delta(d->d_o, d->o, d->delta_ws, d->B, d->H, d->Nq, d->HD, S(stream)) != 0) { g_op_error = "attention_bwd: delta launch failed"; return ACTMI_E_LAUNCH; }
+    AttnBwdArgs a{};
+    a.Q = d->q; a.K = d->k; a.V = d->v; a.dO = d->d_o; a.lse = d->lse; a.delta = d->delta_ws; a.dO_scale = d->do_scale;
+    a.dQ = d->dq; a.dK = d->dk; a.dV = d->dv;
+    a.q_bs = d->q_bs; a.q_rs = d->q_rs; a.k_bs = d->k_bs; a.k_rs = d->k_rs; a.v_bs = d->v_bs; a.v_rs = d->v_rs;
+    a.do_bs = (int64_t)d->Nq * D; a.do_rs = D;
+    a.dq_bs = d->dq_bs; a.dq_rs = d->dq_rs; a.dk_bs = d->dk_bs; a.dk_rs = d->dk_rs; a.dv_bs = d->dv_bs; a.dv_rs = d->dv_rs;
+    a.kpm = d->kpm; a.kpm_bs = d->kpm_bs;
+    a.B = d->B; a.H = d->H; a.Nq = d->Nq; a.Nk = d->Nk; a.HD = d->HD;
+    a.scale = 1.0f / sqrtf((float)d->HD); a.drop_p = d->drop_p; a.drop_seed = d->drop_seed; a.amax_out = d->amax_out;
+    const int rc = launch_attention_bwd(a, S(stream), &g_op_error);
+    return rc == 0 ? ACTMI_OK : (rc == -2 ? ACTMI_E_SHAPE : ACTMI_E_LAUNCH);
+}
+
 int actmi_op_layernorm(const float* x, const float* res, int res_mod, const float* w, const float* b, const float* w2,
                        const float* b2, float* y, int M, int D, float eps, void* stream) {
     g_op_error.clear();

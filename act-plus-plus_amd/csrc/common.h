@@ -122,6 +122,18 @@ int launch_layernorm(const float* x, const float* res, int res_mod, const float*
 // ---- attention (attn.hip) -----------------------------------------------------------------------
 typedef actmi_attn_desc AttnArgs;
 int launch_attention(const AttnArgs& a, hipStream_t st, std::string* err);
+// attention backward without materialised scores (attn_bwd.hip): dQ, dK, dV from Q, K, V, dO, the forward's log-sum-exp and
+// delta[b][h][q] = dO[q] . O[q].  dO_scale (optional, device): the power of two dO is multiplied with on its way into fp16 pieces.
+struct AttnBwdArgs {
+    const float *Q, *K, *V, *dO, *lse, *delta, *dO_scale;
+    float *dQ, *dK, *dV;
+    int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+    const uint8_t* kpm; int64_t kpm_bs;
+    int B, H, Nq, Nk, HD;
+    float scale, drop_p; uint64_t drop_seed;
+    unsigned* amax_out;            // optional: bits of the largest |value| written (integer atomicMax)
+};
+int launch_attention_bwd(const AttnBwdArgs& a, hipStream_t st, std::string* err);
 
 // ---- small kernels (misc.hip) --------------------------------------------------------------------
 int launch_small_linear(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,

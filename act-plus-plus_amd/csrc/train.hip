@@ -242,6 +242,26 @@ struct AttnBwd {
 int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
     TrainState& T = *ctx->train;
     const int G = t.B * t.H, D = t.H * t.HD;
+    {
+        // long sequences (the encoder's 1202 x 1202 self-attention): the fused kernels of attn_bwd.hip -- no P / dS buffers
+        static const bool flash = !(getenv("ACTMI_ATTN_BWD_FLASH") && getenv("ACTMI_ATTN_BWD_FLASH")[0] == '0');
+        if (flash && ctx->gemm_prec == ACTMI_PREC_F16X3 && t.q_bs != 0 && t.Nq >= 256 && t.Nk >= 256 &&
+            (t.HD == 64 || t.HD == 32 || t.HD == 16)) {
+            CHK(launch_attn_delta(t.dO, t.O, T.delta, t.B, t.H, t.Nq, t.HD, st));
+            AttnBwdArgs a{};
+            a.Q = t.Q; a.K = t.K; a.V = t.V; a.dO = t.dO; a.lse = t.lse; a.delta = T.delta;
+            a.dO_scale = dyn_scale(ctx, t.dO, D, t.B * t.Nq, D, st);
+            a.dQ = t.dQ; a.dK = t.dK; a.dV = t.dV;
+            a.q_bs = t.q_bs; a.q_rs = t.q_rs; a.k_bs = t.k_bs; a.k_rs = t.k_rs; a.v_bs = t.v_bs; a.v_rs = t.v_rs;
+            a.do_bs = (int64_t)t.Nq * D; a.do_rs = D;
+            a.dq_bs = t.dq_bs; a.dq_rs = t.dq_rs; a.dk_bs = t.dk_bs; a.dk_rs = t.dk_rs; a.dv_bs = t.dv_bs; a.dv_rs = t.dv_rs;
+            a.kpm = t.kpm; a.kpm_bs = t.kpm_bs;
+            a.B = t.B; a.H = t.H; a.Nq = t.Nq; a.Nk = t.Nk; a.HD = t.HD;
+            a.scale = 1.0f / sqrtf((float)t.HD); a.drop_p = t.drop_p; a.drop_seed = t.drop_seed;
+            a.amax_out = t.out_amax;
+            return launch_attention_bwd(a, st, &ctx->err);
+        }
+    }
     const int ldp = (t.Nk + 3) & ~3;
     const float scale = 1.0f / sqrtf((float)t.HD);
     float* P = T.Pbuf;

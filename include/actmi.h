@@ -308,6 +308,27 @@ int actmi_op_splitk_combine(const float* part, int nsplit, int64_t split_stride,
 int actmi_op_sample_onehot(const float* logits, int n, int V, float temperature, uint64_t seed, float* probs, float* code,
                            void* stream);
 int actmi_op_attention(const actmi_attn_desc* d, void* stream);
+/* Attention backward without materialised scores (training step, long sequences; csrc/attn_bwd.hip): dq / dk / dv of
+ * out = softmax(scale * q k^T [+ key padding mask]) v per (batch, head), from the forward's operands, its output `o`, its
+ * log-sum-exp `lse` [B][H][Nq] (actmi_attn_desc.lse) and the output gradient `d_o`.  q / k / v / dq / dk / dv are addressed by
+ * (batch stride, row stride) as in actmi_attn_desc, heads contiguous blocks of HD floats in a row; o and d_o are [B][Nq][H*HD].
+ * delta_ws: B*H*Nq floats of scratch.  do_scale (optional, device): the power of two d_o is multiplied with on its way into
+ * its fp16 pieces (actmi_op_pow2_scale of d_o); amax_out (optional): bits of the largest |gradient| written.
+ * Replaces autograd through nn.MultiheadAttention's bmm / softmax / dropout / bmm (transformer.py:217-218). */
+typedef struct actmi_attn_bwd_desc {
+    const float *q, *k, *v, *o, *d_o, *lse;
+    float *dq, *dk, *dv;
+    int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+    const uint8_t* kpm;        /* optional key padding mask [B][Nk], nonzero = masked */
+    int64_t kpm_bs;
+    int32_t B, H, Nq, Nk, HD;  /* HD in {16, 32, 64} */
+    float drop_p;
+    uint64_t drop_seed;
+    float* delta_ws;
+    const float* do_scale;
+    uint32_t* amax_out;
+} actmi_attn_bwd_desc;
+int actmi_op_attention_bwd(const actmi_attn_bwd_desc* d, void* stream);
 int actmi_op_layernorm(const float* x, const float* res, int res_mod, const float* w, const float* b, const float* w2,
                        const float* b2, float* y, int M, int D, float eps, void* stream);
 int actmi_op_maxpool3x3s2(const float* in_nhwc, float* out_nhwc, int nimg, int H, int W, int C, void* stream);

@@ -462,3 +462,66 @@ def test_conv_k_order_taps_inner(G, B, H, W, Cin, Cout, stride, prec):
     got = ops.conv2d_nhwc(x, wp.reshape(G, Cout, 3, 3, Cin), bias=bias, relu=True, stride=stride, pad=1, prec=prec,
                           b_scale=256.0 if prec == "f16x3" else 0.0, k_tap_inner=True)
     assert rel_err(got, ref) < 2e-6
+
+
+@pytest.mark.parametrize("B,H,HD,Nq,Nk,pad,dscale", [(2, 8, 64, 300, 300, False, 1.0), (1, 4, 64, 130, 257, True, 1.0),
+                                                      (2, 2, 32, 129, 64, False, 1.0), (1, 4, 16, 70, 200, True, 1.0),
+                                                      (1, 8, 64, 1202, 1202, False, 3e-7)])
+def test_attention_backward_without_materialised_scores(B, H, HD, Nq, Nk, pad, dscale):
+    """csrc/attn_bwd.hip against autograd through softmax(q k^T / sqrt(hd) + mask) v in float64: dq, dk, dv within 2e-5 of each
+    tensor's largest element (ragged tiles, key padding, all head widths, gradients at 3e-7 of unit scale with the device-side
+    operand scale), two runs bit-identical, the amax word equal to the bits of the largest gradient written."""
+    g = torch.Generator().manual_seed(Nq + Nk)
+    D = H * HD
+    qkv = [torch.randn(B, n, D, generator=g, dtype=torch.float64).requires_grad_(True) for n in (Nq, Nk, Nk)]
+    dout = torch.randn(B, Nq, D, generator=g, dtype=torch.float64) * dscale
+    kpm = None
+    if pad:
+        kpm = torch.zeros(B, Nk, dtype=torch.bool)
+        kpm[:, Nk - 37:] = True
+        kpm[0, 5] = True
+    q, k, v = (t.reshape(B, -1, H, HD).transpose(1, 2) for t in qkv)
+    sc = (q @ k.transpose(-1, -2)) / HD ** 0.5
+    if kpm is not None:
+        sc = sc.masked_fill(kpm[:, None, None, :], float("-inf"))
+    out = (sc.softmax(-1) @ v).transpose(1, 2).reshape(B, Nq, D)
+    out.backward(dout)
+    dvc = [t.detach().float().to(dev()) for t in qkv]
+    kd = kpm.to(torch.uint8).to(dev()) if kpm is not None else None
+    o, lse = ops.attention(dvc[0], dvc[1], dvc[2], H, kpm=kd, want_lse=True, prec="f16x3")
+    do = dout.float().to(dev())
+    dsc = ops.pow2_scale(do.view(B * Nq, D)) if dscale != 1.0 else None
+    dq, dk, dv, amax = ops.attention_bwd(dvc[0], dvc[1], dvc[2], o, lse, do, H, kpm=kd, do_scale=dsc, want_amax=True)
+    worst = 0.0
+    for got, ref, name in ((dq, qkv[0].grad, "dq"), (dk, qkv[1].grad, "dk"), (dv, qkv[2].grad, "dv")):
+        err = float((got.cpu().double() - ref).abs().max() / ref.abs().max())
+        worst = max(worst, err)
+        assert err < 2e-5, (name, err)
+    again = ops.attention_bwd(dvc[0], dvc[1], dvc[2], o, lse, do, H, kpm=kd, do_scale=dsc)
+    assert all(torch.equal(a, b) for a, b in zip((dq, dk, dv), again))
+    big = max(float(t.abs().max()) for t in (dq, dk, dv))
+    assert int(amax.item()) == int(torch.tensor(big, dtype=torch.float32).view(torch.int32).item())
+    print(f"attention backward B={B} H={H} hd={HD} {Nq}x{Nk}: worst error {worst:.2e} of the tensor maximum")
+
+
+def test_attention_backward_dropout_masks_match_the_forward():
+    """with the weight dropout on, forward and fused backward must use the same keep(seed, (row, key)) stream: central differences
+    of sum(out * dout) along random directions of q, k, v"""
+    g = torch.Generator().manual_seed(11)
+    B, H, HD, N, p, seed = 1, 4, 64, 260, 0.2, 987
+    D = H * HD
+    q, k, v = (torch.randn(B, N, D, generator=g).to(dev()) for _ in range(3))
+    dout = torch.randn(B, N, D, generator=g).to(dev())
+    o, lse = ops.attention(q, k, v, H, want_lse=True, drop_p=p, drop_seed=seed, prec="f16x3")
+    dq, dk, dv = ops.attention_bwd(q, k, v, o, lse, dout, H, drop_p=p, drop_seed=seed)
+    for idx, (x, gx) in enumerate(((q, dq), (k, dk), (v, dv))):
+        d = torch.randn(x.shape, generator=g).to(dev())
+        eps = 2e-3
+        args = [q, k, v]
+        args[idx] = x + eps * d
+        fp = (ops.attention(*args, H, drop_p=p, drop_seed=seed, prec="f16x3").double() * dout.double()).sum()
+        args[idx] = x - eps * d
+        fm = (ops.attention(*args, H, drop_p=p, drop_seed=seed, prec="f16x3").double() * dout.double()).sum()
+        fd, an = float((fp - fm) / (2 * eps)), float((gx.double() * d.double()).sum())
+        assert abs(fd - an) <= 5e-3 * max(1.0, abs(an)), (idx, fd, an)
+
