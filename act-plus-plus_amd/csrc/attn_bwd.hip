@@ -195,13 +195,13 @@ __device__ __forceinline__ void raise_amax(unsigned* word, float mx) {
 
 // ------------------------------------------------------------------------------------------------------------ dQ
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdK p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdK p) {
     constexpr int NS = HD / 16, DT = (HD + 31) / 32, VD = DT * 32;
     constexpr int KROW = 4 * HD + 16, VROW = 4 * KT + 16;
     __shared__ __attribute__((aligned(16))) unsigned char s_k[KT * KROW];
     __shared__ __attribute__((aligned(16))) unsigned char s_v[KT * KROW];
     __shared__ __attribute__((aligned(16))) unsigned char s_kt[VD * VROW];
-    __shared__ uint8_t s_dead[KT];
+    __shared__ __attribute__((aligned(16))) uint8_t s_dead[KT];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
     int bx, h, b;
     bwd_block_coords(bx, h, b);
@@ -239,17 +239,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdK p) {
             s_dead[t] = (key >= p.Nk) || (kpm && kpm[key < p.Nk ? key : 0] != 0);
         }
         __syncthreads();
-#pragma unroll
+#pragma nounroll
         for (int sub = 0; sub < KT / 32; ++sub) {
             const int kb = kt0 + sub * 32;
             if (kb < p.Nk) {
                 f32x16 S, T;
                 score_tile<HD>(s_k, sub, li, lh, qh, ql, S);
                 score_tile<HD>(s_v, sub, li, lh, gh_, gl_, T);
+                uint32_t dead4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dead4[g] = *reinterpret_cast<const uint32_t*>(s_dead + sub * 32 + 8 * g + 4 * lh);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int kr = sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const float E = s_dead[kr] ? 0.f : __builtin_amdgcn_exp2f(S[e] - lse2);
+                    const float E = ((dead4[e >> 2] >> (8 * (e & 3))) & 0xffu) ? 0.f : __builtin_amdgcn_exp2f(S[e] - lse2);
                     float dp = T[e];
                     if (p.drop_p > 0.f) dp = actmi_keep(p.drop_seed, (uint64_t)rowid * (uint64_t)p.Nk + (uint64_t)(kt0 + kr), p.drop_p) ? dp * dsc : 0.f;
                     S[e] = E * (dp - dlt) * p.scale;            // dS, carrying the scale of dO
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdK p) {
             s_dlt[t] = ok ? p.delta[row0 + qq] * sdo : 0.f;
         }
         __syncthreads();
-#pragma unroll
+#pragma nounroll
         for (int sub = 0; sub < KT / 32; ++sub) {
             const int qb = qt0 + sub * 32;
             if (qb < p.Nq) {
@@ -351,18 +354,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdK p) {
                 score_tile<HD>(s_g, sub, li, lh, vh, vl, T);
                 f32x16 Ed;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int qr = sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const float E = kdead ? 0.f : __builtin_amdgcn_exp2f(S[e] - s_lse[qr]);
-                    float dp = T[e], ed = E;
-                    if (p.drop_p > 0.f) {
-                        const int qq = qt0 + qr < p.Nq ? qt0 + qr : 0;
-                        const bool keep = actmi_keep(p.drop_seed, (uint64_t)(row0 + qq) * (uint64_t)p.Nk + (uint64_t)ks, p.drop_p);
-                        dp = keep ? dp * dsc : 0.f;
-                        ed = keep ? E * dsc : 0.f;
+                for (int g = 0; g < 4; ++g) {           // the 16 rows of this lane: four groups of four consecutive rows
+                    const f32x4 lse4 = *reinterpret_cast<const f32x4*>(s_lse + sub * 32 + 8 * g + 4 * lh);
+                    const f32x4 dlt4 = *reinterpret_cast<const f32x4*>(s_dlt + sub * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * g + j;
+                        const int qr = sub * 32 + j + 8 * g + 4 * lh;
+                        const float E = kdead ? 0.f : __builtin_amdgcn_exp2f(S[e] - lse4[j]);
+                        float dp = T[e], ed = E;
+                        if (p.drop_p > 0.f) {
+                            const int qq = qt0 + qr < p.Nq ? qt0 + qr : 0;
+                            const bool keep = actmi_keep(p.drop_seed, (uint64_t)(row0 + qq) * (uint64_t)p.Nk + (uint64_t)ks, p.drop_p);
+                            dp = keep ? dp * dsc : 0.f;
+                            ed = keep ? E * dsc : 0.f;
+                        }
+                        Ed[e] = ed;
+                        S[e] = E * (dp - dlt4[j]) * p.scale;
                     }
-                    Ed[e] = ed;
-                    S[e] = E * (dp - s_dlt[qr]) * p.scale;
                 }
                 h16x8 fh[2], fl[2];
                 acc_to_frags(Ed, ESC, fh, fl);
