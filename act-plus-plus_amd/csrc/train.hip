@@ -239,14 +239,17 @@ struct AttnBwd {
     unsigned* out_amax;        // optional: one bits word that the dQ, dK and dV products all raise (shared operand scale of gQKV)
 };
 
+// long sequences (the encoder's 1202 x 1202 self-attention) take the fused kernels of attn_bwd.hip: no P / dS buffers
+static bool attn_bwd_fused(const actmi_ctx* ctx, int Nq, int Nk, int HD, bool shared_q) {
+    static const bool flash = !(getenv("ACTMI_ATTN_BWD_FLASH") && getenv("ACTMI_ATTN_BWD_FLASH")[0] == '0');
+    return flash && ctx->gemm_prec == ACTMI_PREC_F16X3 && !shared_q && Nq >= 256 && Nk >= 256 && (HD == 64 || HD == 32 || HD == 16);
+}
+
 int attn_bwd(actmi_ctx* ctx, const AttnBwd& t, hipStream_t st) {
     TrainState& T = *ctx->train;
     const int G = t.B * t.H, D = t.H * t.HD;
     {
-        // long sequences (the encoder's 1202 x 1202 self-attention): the fused kernels of attn_bwd.hip -- no P / dS buffers
-        static const bool flash = !(getenv("ACTMI_ATTN_BWD_FLASH") && getenv("ACTMI_ATTN_BWD_FLASH")[0] == '0');
-        if (flash && ctx->gemm_prec == ACTMI_PREC_F16X3 && t.q_bs != 0 && t.Nq >= 256 && t.Nk >= 256 &&
-            (t.HD == 64 || t.HD == 32 || t.HD == 16)) {
+        if (attn_bwd_fused(ctx, t.Nq, t.Nk, t.HD, t.q_bs == 0)) {
             CHK(launch_attn_delta(t.dO, t.O, T.delta, t.B, t.H, t.Nq, t.HD, st));
             AttnBwdArgs a{};
             a.Q = t.Q; a.K = t.K; a.V = t.V; a.dO = t.dO; a.lse = t.lse; a.delta = T.delta;
@@ -617,7 +620,15 @@ int train_create(actmi_ctx* ctx) {
     const int64_t MN = (int64_t)B * N;
     TA(T.gA, MN * D); TA(T.gB, MN * D); TA(T.gC, MN * D); TA(T.gH, MN * F); TA(T.gQKV, MN * 3 * D);
     const int ldp = (N + 3) & ~3;
-    TA(T.Pbuf, (int64_t)B * H * N * ldp); TA(T.dPbuf, (int64_t)B * H * N * ldp); TA(T.delta, (int64_t)B * H * N);
+    {
+        // materialised P / dS of the attention calls that do not take the fused backward: decoder cross-attention (Q x N), the
+        // CVAE encoder ((Q+2)^2), and -- only without the fused kernels -- the encoder's N x N (2 x 3 GB at B = 64)
+        const int ldq = (Q + 2 + 3) & ~3;
+        int64_t prow = (int64_t)Q * ldp;
+        if ((int64_t)(Q + 2) * ldq > prow) prow = (int64_t)(Q + 2) * ldq;
+        if (!attn_bwd_fused(ctx, N, N, D / H, false) && (int64_t)N * ldp > prow) prow = (int64_t)N * ldp;
+        TA(T.Pbuf, (int64_t)B * H * prow); TA(T.dPbuf, (int64_t)B * H * prow); TA(T.delta, (int64_t)B * H * (N > Q + 2 ? N : Q + 2));
+    }
     TA(T.dXg, (int64_t)B * (C * ctx->P_ > Q ? C * ctx->P_ : Q) * D);
     TA(T.tmp2BD, (int64_t)2 * B * D); TA(T.tmpD, 4 * D); TA(T.dqb, BQ * D);
     {
