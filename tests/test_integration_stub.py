@@ -111,3 +111,42 @@ def test_stub_policy_query_matches_the_oracle():
         exp = R.policy_call(sd, cfg, torch.from_numpy(inp["qpos"]), img).numpy()
     assert np.abs(got - exp).max() <= 1e-4
     ns["lib"].actmi_destroy(pol.h)
+
+
+@pytest.mark.gpu
+def test_stub_training_steps_match_the_package_host_side():
+    """ACTTrainer of the INTEGRATION.md binding (ctypes only): two forward / backward / AdamW steps give the losses the package's
+    own host side (actmi.engine.ACTEngine) gives on the same weights, inputs, eps and dropout 0"""
+    import torch
+    from actmi import weights as W
+    from actmi.config import tiny_config
+    from actmi.engine import ACTEngine
+    ns = _stub_namespace()
+    cfg = tiny_config()
+    B = 2
+    a = dict(camera_names=cfg.camera_names, image_h=cfg.image_h, image_w=cfg.image_w, base_width=cfg.base_width,
+             hidden_dim=cfg.hidden_dim, nheads=cfg.nheads, dim_feedforward=cfg.dim_feedforward, enc_layers=cfg.enc_layers,
+             dec_layers=cfg.dec_layers, num_queries=cfg.num_queries, state_dim=cfg.state_dim, action_dim=cfg.action_dim,
+             no_encoder=False, max_batch=B, kl_weight=cfg.kl_weight, lr=1e-4)
+    sd = W.generate_state_dict(cfg, seed=3)
+    inp = W.generate_inputs(cfg, B, seed=5, with_actions=True)
+    d = "cuda:0"
+    t = {k: torch.from_numpy(v).to(d) for k, v in inp.items()}
+    img_f32 = t["image_u8"].permute(0, 1, 4, 2, 3).float().div(255.0).contiguous()        # the stub feeds f32 NCHW frames
+    tr = ns["ACTTrainer"](a)
+    tr.deserialize({"model." + k: torch.from_numpy(v) for k, v in sd.items()})
+    eng = ACTEngine(cfg, max_batch=B, device=d, training=True)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    for step in range(2):
+        got = tr.loss(t["qpos"], img_f32, t["actions"], t["is_pad"], t["eps"], dropout_p=0.0)
+        tr.backward()
+        tr.step()
+        eng.zero_grad()
+        ref = eng.forward_train(t["qpos"], img_f32, t["actions"], t["is_pad"], eps=t["eps"])
+        eng.backward()
+        eng.adamw_step(1e-4, 1e-5, 1e-4, step=step + 1)
+        for k, kk in (("l1", "l1"), ("kl", "kl"), ("loss", "loss")):
+            assert abs(float(got[k]) - float(ref[kk])) <= 1e-6 * max(1.0, abs(float(ref[kk]))), (step, k, float(got[k]), float(ref[kk]))
+    assert float(got["loss"]) != 0.0
+
