@@ -25,6 +25,8 @@
 namespace {
 
 constexpr int KT = 64;                // rows of the streamed operand per LDS tile
+constexpr int DQ_NT = 256;            // threads of the dQ workgroup (three workgroups per CU = three waves per SIMD; six-wave workgroups do not pack: 2.05 vs 1.27 ms)
+constexpr int DKV_NT = 512;           // threads of the dK / dV workgroup: 8 waves = 256 owned keys share every staged query tile
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 struct AttnBwdK {
@@ -67,14 +69,14 @@ __device__ __forceinline__ void load_row_frags(const float* src, float sc, h16x8
 }
 
 // stage rows [r0, r0 + KT) of a [rows][HD] operand (row stride rs) as [row][HD hi halfs | HD lo halfs] (A operand of a score product)
-template <int HD>
+template <int HD, int NT = 256>
 __device__ __forceinline__ void stage_rows(unsigned char* dst, const float* base, int64_t rs, int r0, int r_end, float sc) {
     constexpr int C4 = HD / 4, KROW = 4 * HD + 16;
-    constexpr int NL = (KT * C4 + 255) / 256;
+    constexpr int NL = (KT * C4 + NT - 1) / NT;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        const int e = threadIdx.x + 256 * i;
+        const int e = threadIdx.x + NT * i;
         if (e < KT * C4) {
             const int kr = e / C4, c = e - kr * C4;
             const int row = r0 + kr;
@@ -91,14 +93,14 @@ __device__ __forceinline__ void stage_rows(unsigned char* dst, const float* base
 
 // the same rows TRANSPOSED: [d][KT rows hi | KT rows lo] with the rows of every 16-group in slot order (0-3, 8-11, 4-7, 12-15):
 // the A operand of an output product whose B operand comes out of score-accumulator registers (attn.hip, V in the forward)
-template <int HD>
+template <int HD, int NT = 256>
 __device__ __forceinline__ void stage_transposed(unsigned char* dst, const float* base, int64_t rs, int r0, int r_end, float sc) {
     constexpr int C4 = HD / 4, VROW = 4 * KT + 16;
-    constexpr int NL = (KT / 2 * C4 + 255) / 256;
+    constexpr int NL = (KT / 2 * C4 + NT - 1) / NT;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        const int e = threadIdx.x + 256 * i;
+        const int e = threadIdx.x + NT * i;
         if (e < KT / 2 * C4) {
             const int c = ((e >> 5) % (C4 / 4)) * 4 + (e & 3);
             const int kp = ((e >> 5) / (C4 / 4)) * 8 + ((e >> 2) & 7);
@@ -195,7 +197,7 @@ __device__ __forceinline__ void raise_amax(unsigned* word, float mx) {
 
 // ------------------------------------------------------------------------------------------------------------ dQ
 template <int HD>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdK p) {
+__global__ __launch_bounds__(DQ_NT, 3) void attn_bwd_dq_kernel(AttnBwdK p) {
     constexpr int NS = HD / 16, DT = (HD + 31) / 32, VD = DT * 32;
     constexpr int KROW = 4 * HD + 16, VROW = 4 * KT + 16;
     __shared__ __attribute__((aligned(16))) unsigned char s_k[KT * KROW];
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdK p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
     int bx, h, b;
     bwd_block_coords(bx, h, b);
-    const int q = bx * 128 + wave * 32 + li;
+    const int q = bx * (DQ_NT / 2) + wave * 32 + li;
     const bool qok = q < p.Nq;
     const int qs = qok ? q : 0;
     const float sdo = p.dO_scale ? *p.dO_scale : 1.f;
@@ -227,13 +229,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdK p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
     if (HD < VD) {
-        for (int e = t; e < VD * VROW / 4; e += 256) reinterpret_cast<uint32_t*>(s_kt)[e] = 0u;
+        for (int e = t; e < VD * VROW / 4; e += DQ_NT) reinterpret_cast<uint32_t*>(s_kt)[e] = 0u;
         __syncthreads();
     }
     for (int kt0 = 0; kt0 < p.Nk; kt0 += KT) {
-        stage_rows<HD>(s_k, Kb, p.k_rs, kt0, p.Nk, 1.f);
-        stage_rows<HD>(s_v, Vb, p.v_rs, kt0, p.Nk, 1.f);
-        stage_transposed<HD>(s_kt, Kb, p.k_rs, kt0, p.Nk, 1.f);
+        stage_rows<HD, DQ_NT>(s_k, Kb, p.k_rs, kt0, p.Nk, 1.f);
+        stage_rows<HD, DQ_NT>(s_v, Vb, p.v_rs, kt0, p.Nk, 1.f);
+        stage_transposed<HD, DQ_NT>(s_kt, Kb, p.k_rs, kt0, p.Nk, 1.f);
         if (t < KT) {
             const int key = kt0 + t;
             s_dead[t] = (key >= p.Nk) || (kpm && kpm[key < p.Nk ? key : 0] != 0);
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnBwdK p) {
 
 // ------------------------------------------------------------------------------------------------------- dK, dV
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdK p) {
+__global__ __launch_bounds__(DKV_NT, 2) void attn_bwd_dkv_kernel(AttnBwdK p) {
     constexpr int NS = HD / 16, DT = (HD + 31) / 32, VD = DT * 32;
     constexpr int KROW = 4 * HD + 16, VROW = 4 * KT + 16;
     constexpr float ESC = 1024.f;                       // fixed split scale of the (dropped) softmax weights
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdK p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
     int bx, h, b;
     bwd_block_coords(bx, h, b);
-    const int key = bx * 128 + wave * 32 + li;
+    const int key = bx * (DKV_NT / 2) + wave * 32 + li;
     const bool kok = key < p.Nk;
     const int ks = kok ? key : 0;
     const uint8_t* kpm = p.kpm ? p.kpm + (int64_t)b * p.kpm_bs : nullptr;
@@ -330,14 +332,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdK p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) { aK[d][e] = 0.f; aV[d][e] = 0.f; }
     if (HD < VD) {
-        for (int e = t; e < VD * VROW / 4; e += 256) { reinterpret_cast<uint32_t*>(s_qt)[e] = 0u; reinterpret_cast<uint32_t*>(s_gt)[e] = 0u; }
+        for (int e = t; e < VD * VROW / 4; e += DKV_NT) { reinterpret_cast<uint32_t*>(s_qt)[e] = 0u; reinterpret_cast<uint32_t*>(s_gt)[e] = 0u; }
         __syncthreads();
     }
     for (int qt0 = 0; qt0 < p.Nq; qt0 += KT) {
-        stage_rows<HD>(s_q, Qb, p.q_rs, qt0, p.Nq, 1.f);
-        stage_rows<HD>(s_g, Gb, p.do_rs, qt0, p.Nq, sdo);
-        stage_transposed<HD>(s_qt, Qb, p.q_rs, qt0, p.Nq, 1.f);
-        stage_transposed<HD>(s_gt, Gb, p.do_rs, qt0, p.Nq, sdo);
+        stage_rows<HD, DKV_NT>(s_q, Qb, p.q_rs, qt0, p.Nq, 1.f);
+        stage_rows<HD, DKV_NT>(s_g, Gb, p.do_rs, qt0, p.Nq, sdo);
+        stage_transposed<HD, DKV_NT>(s_qt, Qb, p.q_rs, qt0, p.Nq, 1.f);
+        stage_transposed<HD, DKV_NT>(s_gt, Gb, p.do_rs, qt0, p.Nq, sdo);
         if (t < KT) {
             const int qq = qt0 + t;
             const bool ok = qq < p.Nq;
@@ -430,13 +432,13 @@ int launch_attention_bwd(const AttnBwdArgs& a, hipStream_t st, std::string* err)
     AttnBwdK k{a.Q, a.K, a.V, a.dO, a.lse, a.delta, a.dO_scale, a.dQ, a.dK, a.dV, a.q_bs, a.q_rs, a.k_bs, a.k_rs, a.v_bs, a.v_rs,
                a.do_bs, a.do_rs, a.dq_bs, a.dq_rs, a.dk_bs, a.dk_rs, a.dv_bs, a.dv_rs, a.kpm, a.kpm_bs, a.B, a.H, a.Nq, a.Nk,
                a.scale, a.drop_p, a.drop_seed, a.amax_out};
-    const dim3 gq((a.Nq + 127) / 128, a.H, a.B), gk((a.Nk + 127) / 128, a.H, a.B);
+    const dim3 gq((a.Nq + DQ_NT / 2 - 1) / (DQ_NT / 2), a.H, a.B), gk((a.Nk + DKV_NT / 2 - 1) / (DKV_NT / 2), a.H, a.B);
     const double f1 = 2.0 * a.B * a.H * (double)a.Nq * a.Nk * a.HD;
     prof_begin("attn_bwd_dq_kernel", 3.0 * f1, 4.0 * a.B * a.H * a.HD * (3.0 * a.Nq + 2.0 * a.Nk), st);
     switch (a.HD) {
-        case 64: hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, st, k); break;
-        case 32: hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(256), 0, st, k); break;
-        default: hipLaunchKernelGGL(attn_bwd_dq_kernel<16>, gq, dim3(256), 0, st, k); break;
+        case 64: hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(DQ_NT), 0, st, k); break;
+        case 32: hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(DQ_NT), 0, st, k); break;
+        default: hipLaunchKernelGGL(attn_bwd_dq_kernel<16>, gq, dim3(DQ_NT), 0, st, k); break;
     }
     prof_end(st);
     prof_begin("attn_bwd_dkv_kernel", 4.0 * f1, 4.0 * a.B * a.H * a.HD * (2.0 * a.Nq + 4.0 * a.Nk), st);
@@ -453,9 +455,9 @@ int launch_attention_bwd(const AttnBwdArgs& a, hipStream_t st, std::string* err)
             attr_set = true;
         }
         switch (a.HD) {
-            case 64: hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(256), lds, st, k); break;
-            case 32: hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, gk, dim3(256), lds, st, k); break;
-            default: hipLaunchKernelGGL(attn_bwd_dkv_kernel<16>, gk, dim3(256), lds, st, k); break;
+            case 64: hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(DKV_NT), lds, st, k); break;
+            case 32: hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, gk, dim3(DKV_NT), lds, st, k); break;
+            default: hipLaunchKernelGGL(attn_bwd_dkv_kernel<16>, gk, dim3(DKV_NT), lds, st, k); break;
         }
     }
     prof_end(st);
