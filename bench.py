@@ -754,14 +754,17 @@ def bench_eval_shard(args, ctx):
              "synthetic_env": True}
     config = IE.build_config(iargs)
     config["episode_len"] = ep_len
-    policy = IE.make_policy("ACT", dict(config["policy_config"], training=False), device=str(dev))
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):             # the host side prints as the reference does: stdout carries the JSON line only
+        policy = IE.make_policy("ACT", dict(config["policy_config"], training=False), device=str(dev))
     policy.eval()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    sr, avg_ret = IE.eval_bc(config, "policy_last.ckpt", save_episode=False, num_rollouts=n_total, policy=policy,
-                             max_parallel=n_local, verbose=(rank == 0))
+    with contextlib.redirect_stdout(sys.stderr):
+        sr, avg_ret = IE.eval_bc(config, "policy_last.ckpt", save_episode=False, num_rollouts=n_total, policy=policy,
+                                 max_parallel=n_local, verbose=(rank == 0))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
