@@ -620,7 +620,7 @@ def train_record(cfg, B, dev, steps, warmup, train_prec=None):
             "train_steps_per_s": steps / dt,
             "arithmetic": ("fp32 storage / accumulation / master weights / AdamW state, ONE bf16 MFMA product per fp32 product in every "
                            "GEMM and implicit-GEMM convolution of the step (opt-in train_prec=bf16: BASELINE config 3 as written; "
-                           "the direct stem / layer1 / attention-forward kernels keep f16x3); dropout 0" if train_prec == "bf16" else
+                           "the direct stem / layer1 kernels and the fused attention kernels, forward and backward, keep f16x3); dropout 0" if train_prec == "bf16" else
                            "fp32 storage and accumulation, f16x3 products forward and backward, fused AdamW; dropout 0 "
                            "(the fp32-grade default step; extra.train_b64_bf16 is the bf16 speed mode)"),
             "achieved_tflops_live": B * steps / dt * GFLOP_TRAIN_PER_SAMPLE_LIVE / 1e3,
